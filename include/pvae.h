@@ -1,0 +1,124 @@
+/* pvae.h -- C ABI of libpvae.so: the MI355X (gfx950) training engine behind popvae.py.
+ *
+ * The reference (/root/reference/popvae.py) has no plugin or FFI surface: its hot path is a sequence of
+ * direct Keras calls.  Each entry point below replaces one of those call sites (cited per function);
+ * INTEGRATION.md shows the ctypes binding a maintainer of popvae.py would add.
+ *
+ * Conventions: one engine handle per GPU rank, single host thread per handle; every function returns 0
+ * on success or a negative code (pvae_last_error gives the text); all host buffers are caller-owned and
+ * copied in/out; no callbacks.  Tensors cross the boundary in Keras layout (Dense kernel = [in][out]
+ * row-major float32) and Keras order: encoder [W1,b1,...,W_D,b_D,Wmu,bmu,Ws,bs], decoder
+ * [V1,c1,...,V_D,c_D,Vout,cout]  (= vae.get_weights()).  Tensors with an SNP axis hold only this rank's
+ * SNP shard [snp_offset, snp_offset + n_snps_local).
+ *
+ * There is no CPU fallback: without a usable HIP device pvae_create fails.
+ */
+#ifndef PVAE_H
+#define PVAE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pvae_engine pvae_engine;
+
+typedef struct pvae_config {
+    int64_t n_snps_local;  /* SNPs held by this rank */
+    int64_t n_snps_global; /* SNPs of the whole model (== local when world == 1) */
+    int64_t snp_offset;    /* first global SNP of this rank's shard */
+    int32_t width;         /* --width  (popvae.py:78-80) */
+    int32_t depth;         /* --depth  (popvae.py:75-77) */
+    int32_t latent_dim;    /* --latent_dim (popvae.py:104-106) */
+    int32_t batch_size;    /* --batch_size (popvae.py:26); at most 32 in this build */
+    float lr, beta1, beta2, eps; /* Keras Adam defaults 1e-3, .9, .999, 1e-7 (popvae.py:426) */
+    int32_t device_id;
+    int32_t rank, world;   /* SNP-axis shard id / count */
+    uint64_t seed;         /* reparameterisation noise stream */
+} pvae_config;
+
+/* library-level */
+const char* pvae_version(void);
+int pvae_device_count(void);
+
+/* model build: encoder/decoder/vae + compile("adam")  -- popvae.py:392-426 */
+int pvae_create(const pvae_config* cfg, pvae_engine** out);
+/* K.clear_session() -- popvae.py:369 */
+int pvae_destroy(pvae_engine* e);
+const char* pvae_last_error(pvae_engine* e);
+/* run all engine work on this hipStream_t (pass torch's current stream); NULL = the engine's own stream */
+int pvae_set_stream(pvae_engine* e, void* hip_stream);
+int pvae_synchronize(pvae_engine* e);
+
+/* genotype matrix: traingen/testgen/dc (popvae.py:237-238,259-267) as ONE resident 2-bit matrix of all N
+ * samples, this rank's SNP columns only; SNP l of a row at bits 2*(l%4) of byte l/4, code = 2*dc value. */
+int pvae_load_genotypes(pvae_engine* e, const uint8_t* packed, int64_t n_samples, int64_t row_bytes);
+
+/* tensors in Keras order -- vae.get_weights()/set_weights(), load_weights (popvae.py:508) */
+int pvae_num_tensors(pvae_engine* e);
+int pvae_tensor_shape(pvae_engine* e, int index, int64_t* rows, int64_t* cols); /* bias: rows = n, cols = 0 */
+int pvae_set_tensor(pvae_engine* e, int index, const float* host, int64_t count);
+int pvae_get_tensor(pvae_engine* e, int index, float* host, int64_t count);
+/* glorot_uniform kernels + zero biases (Keras Dense defaults, popvae.py:394-409); resets Adam state.
+ * The draw for an SNP-axis tensor depends only on (seed, global element index): shards agree. */
+int pvae_init_weights(pvae_engine* e, uint64_t seed);
+/* Adam slot variables (m, v) and iteration count; which: 0 = m, 1 = v */
+int pvae_get_moment(pvae_engine* e, int which, int index, float* host, int64_t count);
+int pvae_reset_optimizer(pvae_engine* e);
+
+/* optimizer.lr (ReduceLROnPlateau, popvae.py:441-450) */
+int pvae_set_lr(pvae_engine* e, float lr);
+int pvae_get_lr(pvae_engine* e, float* lr);
+
+/* one train_step of vae.fit (popvae.py:490): rows = sample indices into the resident matrix (n <= batch_size),
+ * eps = injected N(0,1) [n][latent_dim] or NULL for the engine's own stream.
+ * out3 = {loss, mean reconstruction, mean KL} or NULL (no host sync when NULL). */
+int pvae_train_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3);
+/* one test_step (validation; forward + loss, no update) */
+int pvae_eval_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3);
+/* same forward/backward as pvae_train_step but gradients are stored instead of applied (test hook for
+ * per-step gradient parity); read them back with pvae_get_grad in Keras layout. */
+int pvae_grad_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3);
+int pvae_get_grad(pvae_engine* e, int index, float* host, int64_t count);
+
+/* one epoch of vae.fit(shuffle=True, validation_data=...) (popvae.py:490-498): perm = this epoch's order of
+ * the training rows (K8), batches of batch_size with the short last batch kept, then the validation rows in
+ * order.  loss/val_loss = unweighted means over batches (K9). */
+int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const int32_t* val_rows, int32_t n_val,
+                     float* loss, float* val_loss);
+
+/* encoder.predict (popvae.py:455,509): z_mean/z_log_var/z for the given rows; each [n][latent_dim]; any
+ * output may be NULL.  eps as in pvae_train_step ([n][latent_dim] or NULL). */
+int pvae_encode(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* z_mean, float* z_log_var,
+                float* z);
+/* decoder.predict (scripts/popvae_decoder_tests_HGDP.py:156): probs [n][n_snps_local] from z [n][latent_dim] */
+int pvae_decode(pvae_engine* e, const float* z, int32_t n, float* probs);
+
+/* ModelCheckpoint(save_best_only) + load_weights (popvae.py:429-435,508): device-to-device copy of the
+ * parameters (not the Adam slots) */
+int pvae_snapshot_best(pvae_engine* e);
+int pvae_restore_best(pvae_engine* e);
+
+/* SNP-axis sharding (world > 1): the step is cut at its two exchange points so that the host can run the
+ * all-reduce (RCCL through torch.distributed) on the exchange buffers between the stages.
+ *   stage A: gather/transposes the batch, partial first-layer sums      -> exchange buffer 0 [32][width_padded]
+ *   stage B: narrow forward, fused wide decoder                        -> exchange buffer 1 [32*width_padded + 32]
+ *   stage C: loss, narrow backward (+Adam), wide encoder backward (+Adam)
+ * mode: 0 = train, 1 = eval (stage C only finalises the loss), 2 = gradients only, 3 = encode (A then
+ * pvae_stage_encode).  With world == 1 pvae_train_step is exactly A,B,C back to back. */
+int pvae_exchange_buffer(pvae_engine* e, int which, void** device_ptr, int64_t* n_floats);
+int pvae_stage_a(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, int mode);
+int pvae_stage_b(pvae_engine* e, int mode);
+int pvae_stage_c(pvae_engine* e, int mode, float* out3);
+int pvae_stage_encode(pvae_engine* e, int32_t n, float* z_mean, float* z_log_var, float* z);
+
+/* measurement hook: average device time (ms) of the last call's kernels by name, via hipEvents on the
+ * engine stream; names: "enc_fwd", "dec", "enc_bwd", "narrow_fwd", "narrow_bwd", "gather" */
+int pvae_set_timing(pvae_engine* e, int enabled);
+int pvae_get_timing(pvae_engine* e, const char* name, float* ms_total, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -45,7 +45,7 @@ def build_engine(force=False, extra=()):
     if force or _newer(out, srcs):
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-              "-Wall", "-Wno-unused-function", *extra, "-o", out, main])
+              "-Wall", "-Wno-unused-function", "-Wno-unused-value", *extra, "-o", out, main])
     return out
 
 

@@ -1,0 +1,966 @@
+// pvae_engine.hip -- engine object + C ABI (include/pvae.h) around the gfx950 kernels in pvae_kernels.h.
+//
+// What lives where in HBM (per rank; L = local SNP count padded to 32, Wp = padded width):
+//   geno     N x L/4 bytes          resident 2-bit genotype matrix (all samples, this rank's SNP columns)
+//   W1,m,v   3 x L*Wp floats        wide encoder kernel + Adam slots, fragment-native tiles
+//   V,m,v    3 x L*Wp floats        wide decoder kernel + Adam slots, fragment-native tiles
+//   cb,m,v   3 x L floats           decoder output bias
+//   narrow   (2D-1) dense layers    row-major [in_p][out_p], padded to multiples of 32, + Adam slots
+//   best     1 x params             ModelCheckpoint(save_best_only) snapshot (allocated on first use)
+//   scratch  split-K partials of the two wide kernels, activations, Xt (transposed batch codes)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pvae.h"
+#include "pvae_kernels.h"
+
+#define PV_VERSION "popvae_amd 0.1.0 (gfx950)"
+
+namespace {
+
+struct Buf3 {  // weight + Adam slots (+ lazily allocated gradient dump / best snapshot)
+    float *w = nullptr, *m = nullptr, *v = nullptr, *g = nullptr, *best = nullptr;
+    int64_t n = 0;
+};
+
+struct Dense {  // narrow layer, padded row-major [kin][nout]
+    int kin = 0, nout = 0, act = PV_ACT_LINEAR;
+    Buf3 W, B;
+};
+
+enum TKind { T_W1, T_B1, T_NARROW_W, T_NARROW_B, T_HEAD_W, T_HEAD_B, T_VOUT, T_COUT };
+struct TensorRef {
+    TKind kind;
+    int layer;      // index into narrow[] (or 0/1 = mu/s for heads)
+    int64_t rows, cols;  // Keras shape (cols = 0 for bias)
+};
+
+enum Cat { C_GATHER, C_ENC_FWD, C_NARROW_FWD, C_DEC, C_NARROW_BWD, C_ENC_BWD, C_NCAT };
+const char* kCatNames[C_NCAT] = {"gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd"};
+
+}  // namespace
+
+struct pvae_engine {
+    pvae_config cfg{};
+    std::string err;
+    int dev = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // dims
+    int64_t L = 0, Lp = 0;
+    int nblk = 0, W = 0, Wp = 0, NWB = 0, ngrp = 0, D = 0, K = 0, Kh = 0, Kz = 0;
+    // genotypes
+    uint8_t* geno = nullptr;
+    int64_t n_samples = 0, row_bytes = 0;
+    // parameters
+    Buf3 W1, Vout, cout, b1;
+    std::vector<Dense> enc;  // enc[0..D-2] = hidden layers 2..D
+    Dense heads;             // [Wp][Kh]: cols [0,K) mu, [K,2K) log-var
+    std::vector<Dense> dec;  // dec[0] = K->W linear, dec[1..D-1] elu
+    std::vector<TensorRef> tensors;
+    // activations ([32][ld] row-major)
+    float* P = nullptr;                 // exchange buffer 0: first-layer pre-activation sums [32][Wp]
+    std::vector<float*> h;              // h[0..D-1]
+    float *headout = nullptr, *z = nullptr, *kl = nullptr, *eps = nullptr;
+    std::vector<float*> g;              // g[0..D-1]
+    float* xch1 = nullptr;              // exchange buffer 1: [32*Wp] dg_D + [32] recon
+    float *dA = nullptr, *dB = nullptr, *dpre1 = nullptr, *dheads = nullptr, *dz = nullptr;
+    uint64_t* Xt = nullptr;
+    // scratch
+    float *encpart = nullptr, *dgpart = nullptr, *losspart = nullptr;
+    int enc_wgs = 0, dec_wgs = 0, encb_wgs = 0;
+    // step state
+    PvStep* st = nullptr;
+    int* d_rows = nullptr;
+    int64_t rows_cap = 0;
+    int* d_ntotal = nullptr;
+    uint64_t* d_counter = nullptr;
+    float* d_loss = nullptr;  // [loss_cap][3]
+    int64_t loss_cap = 0;
+    float lr_host = 1e-3f;
+    bool has_best = false;
+    // pinned host staging ring for the per-step API (rows + eps), so that async copies never read caller memory
+    struct Slot { char* host = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
+    Slot slots[8];
+    int slot_next = 0;
+    PvAdam adam{};
+    // timing
+    bool timing = false;
+    struct Ev { hipEvent_t a, b; int cat; };
+    std::vector<Ev> evs;
+    size_t ev_used = 0;
+    double cat_ms[C_NCAT] = {0};
+    int64_t cat_n[C_NCAT] = {0};
+};
+
+namespace {
+
+int set_err(pvae_engine* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _s = (expr);                                                                       \
+        if (_s != hipSuccess)                                                                         \
+            return set_err(e, -10, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_s), __FILE__, __LINE__); \
+    } while (0)
+
+int pad32(int x) { return (x + 31) / 32 * 32; }
+
+int alloc3(pvae_engine* e, Buf3& b, int64_t n) {
+    b.n = n;
+    HIPCHK(hipMalloc(&b.w, n * sizeof(float)));
+    HIPCHK(hipMalloc(&b.m, n * sizeof(float)));
+    HIPCHK(hipMalloc(&b.v, n * sizeof(float)));
+    HIPCHK(hipMemset(b.w, 0, n * sizeof(float)));
+    HIPCHK(hipMemset(b.m, 0, n * sizeof(float)));
+    HIPCHK(hipMemset(b.v, 0, n * sizeof(float)));
+    return 0;
+}
+void free3(Buf3& b) {
+    hipFree(b.w); hipFree(b.m); hipFree(b.v); hipFree(b.g); hipFree(b.best);
+    b = Buf3();
+}
+int allocf(pvae_engine* e, float** p, int64_t n) {
+    HIPCHK(hipMalloc(p, n * sizeof(float)));
+    HIPCHK(hipMemset(*p, 0, n * sizeof(float)));
+    return 0;
+}
+int alloc_dense(pvae_engine* e, Dense& d, int kin, int nout, int act) {
+    d.kin = kin; d.nout = nout; d.act = act;
+    int rc = alloc3(e, d.W, (int64_t)kin * nout);
+    if (rc) return rc;
+    return alloc3(e, d.B, nout);
+}
+
+template <typename F>
+void for_each_buf(pvae_engine* e, F f) {
+    f(e->W1); f(e->b1);
+    for (auto& d : e->enc) { f(d.W); f(d.B); }
+    f(e->heads.W); f(e->heads.B);
+    for (auto& d : e->dec) { f(d.W); f(d.B); }
+    f(e->Vout); f(e->cout);
+}
+
+struct Timer {
+    pvae_engine* e;
+    bool on;
+    size_t idx = 0;
+    Timer(pvae_engine* e_, int cat) : e(e_), on(e_->timing) {
+        if (!on) return;
+        if (e->ev_used == e->evs.size()) {
+            pvae_engine::Ev ev;
+            hipEventCreate(&ev.a);
+            hipEventCreate(&ev.b);
+            e->evs.push_back(ev);
+        }
+        idx = e->ev_used++;
+        e->evs[idx].cat = cat;
+        hipEventRecord(e->evs[idx].a, e->stream);
+    }
+    ~Timer() {
+        if (on) hipEventRecord(e->evs[idx].b, e->stream);
+    }
+};
+
+void flush_timing(pvae_engine* e) {
+    if (!e->ev_used) return;
+    hipStreamSynchronize(e->stream);
+    for (size_t i = 0; i < e->ev_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->evs[i].a, e->evs[i].b) == hipSuccess) {
+            e->cat_ms[e->evs[i].cat] += ms;
+            e->cat_n[e->evs[i].cat] += 1;
+        }
+    }
+    e->ev_used = 0;
+}
+
+// ---- dynamic-LDS sizes ----
+size_t lds_dense_fwd(int K) { return (size_t)(32 * (K + 1) + 4096) * 4; }
+size_t lds_dense_bwd(int N) { return (size_t)(2 * 32 * (N + 1) + 4096) * 4; }
+size_t lds_dec(int NWB) { return (size_t)(32 * (NWB * 32 + 1) + 4 * 3 * 32 * 33) * 4; }
+size_t lds_enc_bwd(int Wp) { return (size_t)32 * Wp * 4; }
+
+template <typename Kern>
+hipError_t allow_lds(Kern k, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+int setup_kernel_attrs(pvae_engine* e) {
+    int maxK = std::max(e->Wp, std::max(e->Kh, e->Kz));
+    HIPCHK(allow_lds(pvk_dense_fwd, lds_dense_fwd(maxK)));
+    HIPCHK(allow_lds(pvk_dense_bwd<PV_MODE_TRAIN>, lds_dense_bwd(maxK)));
+    HIPCHK(allow_lds(pvk_dense_bwd<PV_MODE_GRAD>, lds_dense_bwd(maxK)));
+#define PV_ATTR(N)                                                                    \
+    HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_TRAIN>, lds_dec(N)));                      \
+    HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_GRAD>, lds_dec(N)));                       \
+    HIPCHK(allow_lds(pvk_dec<N, 0, PV_MODE_TRAIN>, lds_dec(N)));                      \
+    HIPCHK(allow_lds(pvk_enc_bwd<N, PV_MODE_TRAIN>, lds_enc_bwd(e->Wp)));             \
+    HIPCHK(allow_lds(pvk_enc_bwd<N, PV_MODE_GRAD>, lds_enc_bwd(e->Wp)));
+    switch (e->NWB) {
+        case 1: PV_ATTR(1) break;
+        case 2: PV_ATTR(2) break;
+        case 3: PV_ATTR(3) break;
+        default: PV_ATTR(4) break;
+    }
+#undef PV_ATTR
+    return 0;
+}
+
+#define PV_DISPATCH_NWB(e, CALL)        \
+    switch ((e)->NWB) {                 \
+        case 1: { constexpr int N_ = 1; CALL; } break; \
+        case 2: { constexpr int N_ = 2; CALL; } break; \
+        case 3: { constexpr int N_ = 3; CALL; } break; \
+        default: { constexpr int N_ = 4; CALL; } break; \
+    }
+
+int launch_check(pvae_engine* e, const char* what) {
+    hipError_t s = hipGetLastError();
+    if (s != hipSuccess) return set_err(e, -11, "launch of %s failed: %s", what, hipGetErrorString(s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / backward building blocks (all asynchronous on e->stream)
+// ------------------------------------------------------------------------------------------------
+int run_dense_fwd(pvae_engine* e, const Dense& d, const float* in, float* out) {
+    hipLaunchKernelGGL(pvk_dense_fwd, dim3(d.nout / 32), dim3(256), lds_dense_fwd(d.kin), e->stream, in, d.kin, d.W.w,
+                       d.B.w, d.nout, d.act, out);
+    return launch_check(e, "dense_fwd");
+}
+
+int run_dense_bwd(pvae_engine* e, Dense& d, const float* in, const float* Y, const float* dY, float* dIn, int mode) {
+    if (mode == PV_MODE_GRAD) {
+        if (!d.W.g) { int rc = allocf(e, &d.W.g, d.W.n); if (rc) return rc; }
+        if (!d.B.g) { int rc = allocf(e, &d.B.g, d.B.n); if (rc) return rc; }
+        hipLaunchKernelGGL(pvk_dense_bwd<PV_MODE_GRAD>, dim3(d.kin / 32), dim3(256), lds_dense_bwd(d.nout), e->stream, in,
+                           d.kin, d.W.w, d.W.g, (float*)nullptr, d.B.w, d.B.g, (float*)nullptr, d.nout, d.act, Y, dY, dIn,
+                           e->st, e->adam);
+    } else {
+        hipLaunchKernelGGL(pvk_dense_bwd<PV_MODE_TRAIN>, dim3(d.kin / 32), dim3(256), lds_dense_bwd(d.nout), e->stream, in,
+                           d.kin, d.W.w, d.W.m, d.W.v, d.B.w, d.B.m, d.B.v, d.nout, d.act, Y, dY, dIn, e->st, e->adam);
+    }
+    return launch_check(e, "dense_bwd");
+}
+
+// stage A: batch gather/transposes + partial wide-encoder sums -> P (pre-bias, this rank's SNPs only)
+int stage_a(pvae_engine* e, int row_offset, bool need_xt) {
+    int rc;
+    if (!e->geno) return set_err(e, -3, "no genotypes loaded (pvae_load_genotypes)");
+    if (need_xt) {
+        Timer t(e, C_GATHER);
+        int pairs = (e->nblk + 1) / 2;
+        hipLaunchKernelGGL(pvk_gather_transpose, dim3((pairs + 3) / 4), dim3(256), 0, e->stream, e->geno, e->row_bytes,
+                           e->d_rows, e->st, row_offset, e->nblk, e->Xt);
+        if ((rc = launch_check(e, "gather_transpose"))) return rc;
+    }
+    {
+        Timer t(e, C_ENC_FWD);
+        PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_enc_fwd<N_>, dim3(e->enc_wgs), dim3(256), 0, e->stream, e->W1.w, e->geno,
+                                              e->row_bytes, e->d_rows, e->st, row_offset, e->nblk, e->ngrp, e->encpart));
+        if ((rc = launch_check(e, "enc_fwd"))) return rc;
+        PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_enc_reduce<N_>, dim3((N_ * 1024 + 255) / 256, e->ngrp), dim3(256), 0,
+                                              e->stream, e->encpart, e->enc_wgs * 4, e->ngrp, e->Wp, e->P));
+        if ((rc = launch_check(e, "enc_reduce"))) return rc;
+    }
+    return 0;
+}
+
+// narrow encoder: h1 = elu(P + b1), hidden layers, heads, reparameterisation + KL
+int narrow_encoder(pvae_engine* e) {
+    int rc;
+    hipLaunchKernelGGL(pvk_bias_act, dim3((32 * e->Wp + 255) / 256), dim3(256), 0, e->stream, e->P, e->b1.w, e->Wp,
+                       (int)PV_ACT_ELU, e->h[0]);
+    if ((rc = launch_check(e, "bias_act"))) return rc;
+    for (int i = 0; i < e->D - 1; ++i)
+        if ((rc = run_dense_fwd(e, e->enc[i], e->h[i], e->h[i + 1]))) return rc;
+    if ((rc = run_dense_fwd(e, e->heads, e->h[e->D - 1], e->headout))) return rc;
+    hipLaunchKernelGGL(pvk_reparam, dim3(1), dim3(64), 0, e->stream, e->headout, e->Kh, e->K, e->eps, e->z, e->Kz, e->kl);
+    return launch_check(e, "reparam");
+}
+
+int narrow_decoder(pvae_engine* e) {
+    int rc;
+    if ((rc = run_dense_fwd(e, e->dec[0], e->z, e->g[0]))) return rc;
+    for (int i = 1; i < e->D; ++i)
+        if ((rc = run_dense_fwd(e, e->dec[i], e->g[i - 1], e->g[i]))) return rc;
+    return 0;
+}
+
+// stage B: narrow forward + fused wide decoder -> xch1 (dg partial sums over this rank's SNPs, recon sums)
+int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
+    int rc;
+    {
+        Timer t(e, C_NARROW_FWD);
+        if ((rc = narrow_encoder(e))) return rc;
+        if ((rc = narrow_decoder(e))) return rc;
+    }
+    {
+        Timer t(e, C_DEC);
+        const float* gD = e->g[e->D - 1];
+        if (mode == 2 && !e->Vout.g) {
+            if ((rc = allocf(e, &e->Vout.g, e->Vout.n))) return rc;
+            if ((rc = allocf(e, &e->cout.g, e->cout.n))) return rc;
+        }
+        if (mode == 0) {
+            PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 1, PV_MODE_TRAIN>), dim3(e->dec_wgs), dim3(256), lds_dec(N_),
+                                                  e->stream, e->Vout.w, e->Vout.m, e->Vout.v, e->cout.w, e->cout.m,
+                                                  e->cout.v, gD, e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart,
+                                                  e->losspart));
+        } else if (mode == 2) {
+            PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 1, PV_MODE_GRAD>), dim3(e->dec_wgs), dim3(256), lds_dec(N_),
+                                                  e->stream, e->Vout.w, e->Vout.g, (float*)nullptr, e->cout.w, e->cout.g,
+                                                  (float*)nullptr, gD, e->Xt, e->nblk, (int)e->L, e->st, e->adam,
+                                                  e->dgpart, e->losspart));
+        } else {
+            PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 0, PV_MODE_TRAIN>), dim3(e->dec_wgs), dim3(256), lds_dec(N_),
+                                                  e->stream, e->Vout.w, (float*)nullptr, (float*)nullptr, e->cout.w,
+                                                  (float*)nullptr, (float*)nullptr, gD, e->Xt, e->nblk, (int)e->L, e->st,
+                                                  e->adam, e->dgpart, e->losspart));
+        }
+        if ((rc = launch_check(e, "dec"))) return rc;
+        const int n_dg = mode == 1 ? 0 : 32 * e->Wp;
+        // eval: only the recon sums are produced (they live behind the dg block of the exchange buffer)
+        hipLaunchKernelGGL(pvk_dec_reduce, dim3((32 * e->Wp + 32 + 255) / 256), dim3(256), 0, e->stream, e->dgpart,
+                           e->losspart, e->dec_wgs, n_dg, e->xch1,
+                           e->xch1 + 32 * e->Wp);
+        if ((rc = launch_check(e, "dec_reduce"))) return rc;
+    }
+    return 0;
+}
+
+// stage C: loss, narrow backward (+Adam), wide encoder backward (+Adam)
+int stage_c(pvae_engine* e, int mode, float* d_out3) {
+    int rc;
+    hipLaunchKernelGGL(pvk_loss_final, dim3(1), dim3(64), 0, e->stream, e->xch1 + 32 * e->Wp, e->kl, e->st, d_out3);
+    if ((rc = launch_check(e, "loss_final"))) return rc;
+    if (mode == 1) return 0;
+    const int km = mode == 2 ? PV_MODE_GRAD : PV_MODE_TRAIN;
+    {
+        Timer t(e, C_NARROW_BWD);
+        const int D = e->D;
+        // decoder hidden layers D-1..1 (elu) then layer 0 (linear): dY ping-pongs between xch1/dA/dB
+        const float* dY = e->xch1;
+        float* bufs[2] = {e->dA, e->dB};
+        int pp = 0;
+        for (int i = D - 1; i >= 1; --i) {
+            if ((rc = run_dense_bwd(e, e->dec[i], e->g[i - 1], e->g[i], dY, bufs[pp], km))) return rc;
+            dY = bufs[pp];
+            pp ^= 1;
+        }
+        if ((rc = run_dense_bwd(e, e->dec[0], e->z, e->g[0], dY, e->dz, km))) return rc;
+        hipLaunchKernelGGL(pvk_reparam_bwd, dim3(1), dim3(64), 0, e->stream, e->headout, e->Kh, e->K, e->eps, e->dz, e->Kz,
+                           e->dheads, e->st);
+        if ((rc = launch_check(e, "reparam_bwd"))) return rc;
+        if ((rc = run_dense_bwd(e, e->heads, e->h[D - 1], e->headout, e->dheads, bufs[pp], km))) return rc;
+        dY = bufs[pp];
+        pp ^= 1;
+        for (int i = D - 2; i >= 0; --i) {
+            if ((rc = run_dense_bwd(e, e->enc[i], e->h[i], e->h[i + 1], dY, bufs[pp], km))) return rc;
+            dY = bufs[pp];
+            pp ^= 1;
+        }
+        // first (wide) layer: dpre1 + b1
+        if (km == PV_MODE_GRAD) {
+            if (!e->b1.g && (rc = allocf(e, &e->b1.g, e->b1.n))) return rc;
+            hipLaunchKernelGGL(pvk_bias_bwd<PV_MODE_GRAD>, dim3((e->Wp + 63) / 64), dim3(64), 0, e->stream, e->h[0], dY,
+                               e->Wp, (int)PV_ACT_ELU, e->dpre1, e->b1.w, e->b1.g, (float*)nullptr, e->st, e->adam);
+        } else {
+            hipLaunchKernelGGL(pvk_bias_bwd<PV_MODE_TRAIN>, dim3((e->Wp + 63) / 64), dim3(64), 0, e->stream, e->h[0], dY,
+                               e->Wp, (int)PV_ACT_ELU, e->dpre1, e->b1.w, e->b1.m, e->b1.v, e->st, e->adam);
+        }
+        if ((rc = launch_check(e, "bias_bwd"))) return rc;
+    }
+    {
+        Timer t(e, C_ENC_BWD);
+        if (km == PV_MODE_GRAD) {
+            if (!e->W1.g && (rc = allocf(e, &e->W1.g, e->W1.n))) return rc;
+            PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_GRAD>), dim3(e->encb_wgs), dim3(256),
+                                                  lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.g, (float*)nullptr, e->dpre1,
+                                                  e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam));
+        } else {
+            PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN>), dim3(e->encb_wgs), dim3(256),
+                                                  lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->dpre1, e->Wp,
+                                                  e->Xt, e->nblk, e->ngrp, e->st, e->adam));
+        }
+        if ((rc = launch_check(e, "enc_bwd"))) return rc;
+    }
+    return 0;
+}
+
+int ensure_rows(pvae_engine* e, int64_t n) {
+    if (n <= e->rows_cap) return 0;
+    if (e->d_rows) hipFree(e->d_rows);
+    e->rows_cap = std::max<int64_t>(n, 4096);
+    HIPCHK(hipMalloc(&e->d_rows, e->rows_cap * sizeof(int)));
+    return 0;
+}
+int ensure_loss(pvae_engine* e, int64_t steps) {
+    if (steps <= e->loss_cap) return 0;
+    if (e->d_loss) hipFree(e->d_loss);
+    e->loss_cap = std::max<int64_t>(steps, 1024);
+    HIPCHK(hipMalloc(&e->d_loss, e->loss_cap * 3 * sizeof(float)));
+    return 0;
+}
+
+int check_rows(pvae_engine* e, const int32_t* rows, int64_t n) {
+    for (int64_t i = 0; i < n; ++i)
+        if (rows[i] < 0 || rows[i] >= e->n_samples)
+            return set_err(e, -4, "row index %d out of range [0, %lld)", rows[i], (long long)e->n_samples);
+    return 0;
+}
+
+// upload rows/eps for a single batch and run pvk_step_begin
+constexpr size_t kSlotBytes = 32 * sizeof(int) + 32 * 16 * sizeof(float);
+int begin_batch(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, bool train) {
+    int rc;
+    if (n <= 0 || n > e->cfg.batch_size) return set_err(e, -2, "batch of %d rows (batch_size %d)", n, e->cfg.batch_size);
+    if (!e->geno) return set_err(e, -3, "no genotypes loaded (pvae_load_genotypes)");
+    if ((rc = check_rows(e, rows, n))) return rc;
+    if ((rc = ensure_rows(e, n))) return rc;
+    pvae_engine::Slot& sl = e->slots[e->slot_next];
+    e->slot_next = (e->slot_next + 1) % 8;
+    if (!sl.host) {
+        HIPCHK(hipHostMalloc((void**)&sl.host, kSlotBytes, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    }
+    if (sl.pending) HIPCHK(hipEventSynchronize(sl.ev));
+    memcpy(sl.host, rows, n * sizeof(int));
+    if (eps) memcpy(sl.host + 32 * sizeof(int), eps, (size_t)n * e->K * sizeof(float));
+    HIPCHK(hipMemcpyAsync(e->d_rows, sl.host, n * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(pvk_step_begin, dim3(1), dim3(64), 0, e->stream, e->st, (const int*)nullptr, n, e->cfg.batch_size, 0,
+                       train ? 1 : 0, e->adam.b1, e->adam.b2);
+    if ((rc = launch_check(e, "step_begin"))) return rc;
+    if (eps) {
+        HIPCHK(hipMemcpyAsync(e->eps, sl.host + 32 * sizeof(int), (size_t)n * e->K * sizeof(float), hipMemcpyHostToDevice,
+                              e->stream));
+        HIPCHK(hipEventRecord(sl.ev, e->stream));
+        sl.pending = true;
+    } else {
+        HIPCHK(hipEventRecord(sl.ev, e->stream));
+        sl.pending = true;
+        hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, 32 * e->K, e->cfg.seed, e->d_counter);
+        if ((rc = launch_check(e, "gen_eps"))) return rc;
+    }
+    return 0;
+}
+
+int fetch_out3(pvae_engine* e, float* out3) {
+    if (!out3) return 0;
+    HIPCHK(hipMemcpyAsync(out3, e->d_loss, 3 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int full_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3, int mode) {
+    int rc;
+    if (e->cfg.world != 1)
+        return set_err(e, -5, "world > 1: drive the step through pvae_stage_a/b/c with all-reduces in between");
+    if ((rc = ensure_loss(e, 1))) return rc;
+    if ((rc = begin_batch(e, rows, n, eps, mode == 0))) return rc;
+    if ((rc = stage_a(e, 0, true))) return rc;
+    if ((rc = stage_b(e, mode))) return rc;
+    if ((rc = stage_c(e, mode, e->d_loss))) return rc;
+    return fetch_out3(e, out3);
+}
+
+// tensor <-> storage plumbing -------------------------------------------------------------------
+float* pick(Buf3& b, int which) { return which == 0 ? b.w : which == 1 ? b.m : which == 2 ? b.v : b.g; }
+
+int tensor_io(pvae_engine* e, int index, int which, float* host, int64_t count, bool to_device) {
+    if (index < 0 || index >= (int)e->tensors.size()) return set_err(e, -2, "tensor index %d out of range", index);
+    const TensorRef& t = e->tensors[index];
+    const int64_t expect = t.cols ? t.rows * t.cols : t.rows;
+    if (count != expect) return set_err(e, -2, "tensor %d holds %lld floats, got %lld", index, (long long)expect, (long long)count);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    auto narrow2d = [&](float* dev, int ld, int col0) -> int {
+        // Keras [rows][cols] <-> padded device [.][ld] at column col0
+        if (to_device)
+            HIPCHK(hipMemcpy2D(dev + col0, (size_t)ld * 4, host, (size_t)t.cols * 4, (size_t)t.cols * 4, (size_t)t.rows, hipMemcpyHostToDevice));
+        else
+            HIPCHK(hipMemcpy2D(host, (size_t)t.cols * 4, dev + col0, (size_t)ld * 4, (size_t)t.cols * 4, (size_t)t.rows, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    auto vec = [&](float* dev, int off) -> int {
+        if (to_device) HIPCHK(hipMemcpy(dev + off, host, (size_t)t.rows * 4, hipMemcpyHostToDevice));
+        else HIPCHK(hipMemcpy(host, dev + off, (size_t)t.rows * 4, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    auto need = [&](Buf3& b) -> int {
+        if (!pick(b, which)) return set_err(e, -6, "tensor %d: requested buffer not available (run pvae_grad_step first)", index);
+        return 0;
+    };
+    int rc;
+    switch (t.kind) {
+        case T_W1:
+        case T_VOUT: {
+            Buf3& b = t.kind == T_W1 ? e->W1 : e->Vout;
+            if ((rc = need(b))) return rc;
+            float* tmp = nullptr;
+            HIPCHK(hipMalloc(&tmp, (size_t)expect * 4));
+            if (to_device) HIPCHK(hipMemcpy(tmp, host, (size_t)expect * 4, hipMemcpyHostToDevice));
+            const int64_t total = b.n;
+            hipLaunchKernelGGL(pvk_convert_wide, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, pick(b, which),
+                               tmp, t.kind == T_W1 ? 0 : 1, to_device ? 0 : 1, e->L, e->W, e->nblk, e->ngrp, e->NWB);
+            if ((rc = launch_check(e, "convert_wide"))) { hipFree(tmp); return rc; }
+            HIPCHK(hipStreamSynchronize(e->stream));
+            if (!to_device) HIPCHK(hipMemcpy(host, tmp, (size_t)expect * 4, hipMemcpyDeviceToHost));
+            hipFree(tmp);
+            return 0;
+        }
+        case T_B1: if ((rc = need(e->b1))) return rc; return vec(pick(e->b1, which), 0);
+        case T_COUT: if ((rc = need(e->cout))) return rc; return vec(pick(e->cout, which), 0);
+        case T_NARROW_W: {
+            Dense& d = t.layer < 1000 ? e->enc[t.layer] : e->dec[t.layer - 1000];
+            if ((rc = need(d.W))) return rc;
+            return narrow2d(pick(d.W, which), d.nout, 0);
+        }
+        case T_NARROW_B: {
+            Dense& d = t.layer < 1000 ? e->enc[t.layer] : e->dec[t.layer - 1000];
+            if ((rc = need(d.B))) return rc;
+            return vec(pick(d.B, which), 0);
+        }
+        case T_HEAD_W: if ((rc = need(e->heads.W))) return rc; return narrow2d(pick(e->heads.W, which), e->Kh, t.layer * e->K);
+        case T_HEAD_B: if ((rc = need(e->heads.B))) return rc; return vec(pick(e->heads.B, which), t.layer * e->K);
+    }
+    return set_err(e, -2, "bad tensor kind");
+}
+
+// counter-based uniform in [0,1): splitmix64 of (seed, tensor, global element index)
+inline float hash_uniform(uint64_t seed, uint64_t tensor, uint64_t idx) {
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + tensor * 0xD1B54A32D192ED03ull + idx;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (float)((x >> 40) + 0.5) * (1.0f / 16777216.0f);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pvae_version(void) { return PV_VERSION; }
+
+int pvae_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static thread_local std::string g_create_err;
+const char* pvae_last_error(pvae_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+int pvae_create(const pvae_config* cfg, pvae_engine** out) {
+    if (!cfg || !out) return -1;
+    *out = nullptr;
+    pvae_engine* e = new pvae_engine();
+    e->cfg = *cfg;
+    auto bail = [&](int rc) {
+        g_create_err = e->err;
+        pvae_destroy(e);
+        return rc;
+    };
+    if (cfg->n_snps_local <= 0 || cfg->width <= 0 || cfg->depth < 1 || cfg->latent_dim < 1)
+        return bail(set_err(e, -2, "bad dimensions"));
+    if (cfg->batch_size < 1 || cfg->batch_size > 32)
+        return bail(set_err(e, -2, "batch_size %d unsupported: this build handles 1..32 rows per step", cfg->batch_size));
+    if (cfg->width > 128) return bail(set_err(e, -2, "width %d unsupported: this build handles widths up to 128", cfg->width));
+    if (cfg->latent_dim > 16) return bail(set_err(e, -2, "latent_dim %d unsupported (max 16)", cfg->latent_dim));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return bail(set_err(e, -20, "no HIP device visible: popvae_amd has no CPU fallback"));
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return bail(set_err(e, -2, "device_id %d of %d", cfg->device_id, ndev));
+    e->dev = cfg->device_id;
+#define CK(x) do { int rc_ = (x); if (rc_) return bail(rc_); } while (0)
+#define HK(x) do { hipError_t s_ = (x); if (s_ != hipSuccess) return bail(set_err(e, -10, "%s: %s", #x, hipGetErrorString(s_))); } while (0)
+    HK(hipSetDevice(e->dev));
+    HK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    e->stream = e->own_stream;
+    e->L = cfg->n_snps_local;
+    e->nblk = (int)((e->L + 31) / 32);
+    e->Lp = (int64_t)e->nblk * 32;
+    e->W = cfg->width;
+    e->Wp = pad32(e->W);
+    e->NWB = e->Wp / 32;
+    e->ngrp = 1;
+    e->D = cfg->depth;
+    e->K = cfg->latent_dim;
+    e->Kh = pad32(2 * e->K);
+    e->Kz = pad32(e->K);
+    e->adam = PvAdam{cfg->beta1, cfg->beta2, cfg->eps};
+    e->lr_host = cfg->lr;
+
+    const int64_t wide_n = (int64_t)e->nblk * e->ngrp * e->NWB * 1024;
+    CK(alloc3(e, e->W1, wide_n));
+    CK(alloc3(e, e->Vout, wide_n));
+    CK(alloc3(e, e->cout, e->Lp));
+    CK(alloc3(e, e->b1, e->Wp));
+    e->enc.resize(e->D - 1);
+    for (auto& d : e->enc) CK(alloc_dense(e, d, e->Wp, e->Wp, PV_ACT_ELU));
+    CK(alloc_dense(e, e->heads, e->Wp, e->Kh, PV_ACT_LINEAR));
+    e->dec.resize(e->D);
+    CK(alloc_dense(e, e->dec[0], e->Kz, e->Wp, PV_ACT_LINEAR));
+    for (int i = 1; i < e->D; ++i) CK(alloc_dense(e, e->dec[i], e->Wp, e->Wp, PV_ACT_ELU));
+
+    // Keras tensor order
+    auto& T = e->tensors;
+    T.push_back({T_W1, 0, e->L, e->W});
+    T.push_back({T_B1, 0, e->W, 0});
+    for (int i = 0; i < e->D - 1; ++i) {
+        T.push_back({T_NARROW_W, i, e->W, e->W});
+        T.push_back({T_NARROW_B, i, e->W, 0});
+    }
+    T.push_back({T_HEAD_W, 0, e->W, e->K});
+    T.push_back({T_HEAD_B, 0, e->K, 0});
+    T.push_back({T_HEAD_W, 1, e->W, e->K});
+    T.push_back({T_HEAD_B, 1, e->K, 0});
+    T.push_back({T_NARROW_W, 1000, e->K, e->W});
+    T.push_back({T_NARROW_B, 1000, e->W, 0});
+    for (int i = 1; i < e->D; ++i) {
+        T.push_back({T_NARROW_W, 1000 + i, e->W, e->W});
+        T.push_back({T_NARROW_B, 1000 + i, e->W, 0});
+    }
+    T.push_back({T_VOUT, 0, e->W, e->L});
+    T.push_back({T_COUT, 0, e->L, 0});
+
+    // activations / scratch
+    const int64_t act_n = 32 * (int64_t)std::max(e->Wp, std::max(e->Kh, e->Kz));
+    CK(allocf(e, &e->P, 32 * e->Wp));
+    e->h.resize(e->D);
+    e->g.resize(e->D);
+    for (auto& p : e->h) CK(allocf(e, &p, 32 * e->Wp));
+    for (auto& p : e->g) CK(allocf(e, &p, 32 * e->Wp));
+    CK(allocf(e, &e->headout, 32 * e->Kh));
+    CK(allocf(e, &e->dheads, 32 * e->Kh));
+    CK(allocf(e, &e->z, 32 * e->Kz));
+    CK(allocf(e, &e->dz, 32 * e->Kz));
+    CK(allocf(e, &e->kl, 32));
+    CK(allocf(e, &e->eps, 32 * e->K));
+    CK(allocf(e, &e->xch1, 32 * e->Wp + 32));
+    CK(allocf(e, &e->dA, act_n));
+    CK(allocf(e, &e->dB, act_n));
+    CK(allocf(e, &e->dpre1, 32 * e->Wp));
+    HK(hipMalloc(&e->Xt, e->Lp * sizeof(uint64_t)));
+    HK(hipMemset(e->Xt, 0, e->Lp * sizeof(uint64_t)));
+
+    const int64_t tasks = (int64_t)e->nblk * e->ngrp;
+    auto clampi = [](int64_t v, int64_t lo, int64_t hi) { return (int)std::min(hi, std::max(lo, v)); };
+    e->enc_wgs = clampi((tasks + 15) / 16, 1, 512);
+    e->dec_wgs = clampi((e->nblk + 7) / 8, 1, 512);
+    e->encb_wgs = clampi((tasks + 7) / 8, 1, 1024);
+    CK(allocf(e, &e->encpart, (int64_t)e->enc_wgs * 4 * e->NWB * 1024));
+    CK(allocf(e, &e->dgpart, (int64_t)e->dec_wgs * 32 * e->Wp));
+    CK(allocf(e, &e->losspart, (int64_t)e->dec_wgs));
+
+    HK(hipMalloc(&e->st, sizeof(PvStep)));
+    PvStep st0{};
+    st0.lr = cfg->lr;
+    HK(hipMemcpy(e->st, &st0, sizeof st0, hipMemcpyHostToDevice));
+    HK(hipMalloc(&e->d_ntotal, sizeof(int)));
+    HK(hipMalloc(&e->d_counter, sizeof(uint64_t)));
+    HK(hipMemset(e->d_counter, 0, sizeof(uint64_t)));
+    CK(ensure_rows(e, 4096));
+    CK(ensure_loss(e, 1024));
+    CK(setup_kernel_attrs(e));
+#undef CK
+#undef HK
+    *out = e;
+    return 0;
+}
+
+int pvae_destroy(pvae_engine* e) {
+    if (!e) return 0;
+    hipSetDevice(e->dev);
+    if (e->own_stream) hipStreamSynchronize(e->own_stream);
+    for_each_buf(e, [](Buf3& b) { free3(b); });
+    for (auto p : e->h) hipFree(p);
+    for (auto p : e->g) hipFree(p);
+    float* fl[] = {e->P, e->headout, e->dheads, e->z, e->dz, e->kl, e->eps, e->xch1, e->dA, e->dB, e->dpre1,
+                   e->encpart, e->dgpart, e->losspart, e->d_loss};
+    for (auto p : fl) hipFree(p);
+    hipFree(e->Xt); hipFree(e->geno); hipFree(e->st); hipFree(e->d_rows); hipFree(e->d_ntotal); hipFree(e->d_counter);
+    for (auto& ev : e->evs) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+    for (auto& sl : e->slots) { if (sl.host) hipHostFree(sl.host); if (sl.ev) hipEventDestroy(sl.ev); }
+    if (e->own_stream) hipStreamDestroy(e->own_stream);
+    delete e;
+    return 0;
+}
+
+int pvae_set_stream(pvae_engine* e, void* s) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->stream = s ? (hipStream_t)s : e->own_stream;
+    return 0;
+}
+
+int pvae_synchronize(pvae_engine* e) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int pvae_load_genotypes(pvae_engine* e, const uint8_t* packed, int64_t n_samples, int64_t row_bytes) {
+    if (row_bytes < e->Lp / 4 || row_bytes % 8) return set_err(e, -2, "row_bytes %lld: need a multiple of 8 >= %lld", (long long)row_bytes, (long long)(e->Lp / 4));
+    if (n_samples <= 0) return set_err(e, -2, "no samples");
+    // reject the reserved "missing" code 3: the reference imputes before training (popvae.py:231-235)
+    for (int64_t i = 0; i < n_samples; ++i) {
+        const uint8_t* r = packed + i * row_bytes;
+        for (int64_t j = 0; j < e->Lp / 4; ++j)
+            if (r[j] & (r[j] >> 1) & 0x55) return set_err(e, -2, "genotype code 3 (missing) at sample %lld: impute first", (long long)i);
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->geno) hipFree(e->geno);
+    e->geno = nullptr;
+    HIPCHK(hipMalloc(&e->geno, (size_t)(n_samples * row_bytes)));
+    HIPCHK(hipMemcpy(e->geno, packed, (size_t)(n_samples * row_bytes), hipMemcpyHostToDevice));
+    e->n_samples = n_samples;
+    e->row_bytes = row_bytes;
+    return 0;
+}
+
+int pvae_num_tensors(pvae_engine* e) { return (int)e->tensors.size(); }
+
+int pvae_tensor_shape(pvae_engine* e, int index, int64_t* rows, int64_t* cols) {
+    if (index < 0 || index >= (int)e->tensors.size()) return set_err(e, -2, "tensor index %d out of range", index);
+    *rows = e->tensors[index].rows;
+    *cols = e->tensors[index].cols;
+    return 0;
+}
+
+int pvae_set_tensor(pvae_engine* e, int index, const float* host, int64_t count) {
+    return tensor_io(e, index, 0, const_cast<float*>(host), count, true);
+}
+int pvae_get_tensor(pvae_engine* e, int index, float* host, int64_t count) { return tensor_io(e, index, 0, host, count, false); }
+int pvae_get_moment(pvae_engine* e, int which, int index, float* host, int64_t count) {
+    if (which != 0 && which != 1) return set_err(e, -2, "which must be 0 (m) or 1 (v)");
+    return tensor_io(e, index, 1 + which, host, count, false);
+}
+int pvae_get_grad(pvae_engine* e, int index, float* host, int64_t count) { return tensor_io(e, index, 3, host, count, false); }
+
+int pvae_reset_optimizer(pvae_engine* e) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int rc = 0;
+    for_each_buf(e, [&](Buf3& b) {
+        if (hipMemset(b.m, 0, b.n * 4) != hipSuccess || hipMemset(b.v, 0, b.n * 4) != hipSuccess) rc = -10;
+    });
+    if (rc) return set_err(e, rc, "hipMemset failed");
+    PvStep st0{};
+    st0.lr = e->lr_host;
+    HIPCHK(hipMemcpy(e->st, &st0, sizeof st0, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int pvae_init_weights(pvae_engine* e, uint64_t seed) {
+    int rc;
+    std::vector<float> buf;
+    for (int ti = 0; ti < (int)e->tensors.size(); ++ti) {
+        const TensorRef& t = e->tensors[ti];
+        const int64_t n = t.cols ? t.rows * t.cols : t.rows;
+        buf.assign((size_t)n, 0.f);
+        if (t.cols) {
+            // glorot_uniform with the GLOBAL fans (an SNP shard is a slice of the full kernel)
+            const int64_t fr = t.kind == T_W1 ? e->cfg.n_snps_global : t.rows;
+            const int64_t fc = t.kind == T_VOUT ? e->cfg.n_snps_global : t.cols;
+            const float lim = std::sqrt(6.0f / (float)(fr + fc));
+            for (int64_t r = 0; r < t.rows; ++r)
+                for (int64_t c = 0; c < t.cols; ++c) {
+                    uint64_t gidx;
+                    if (t.kind == T_W1) gidx = (uint64_t)(e->cfg.snp_offset + r) * t.cols + c;
+                    else if (t.kind == T_VOUT) gidx = (uint64_t)r * e->cfg.n_snps_global + e->cfg.snp_offset + c;
+                    else gidx = (uint64_t)r * t.cols + c;
+                    buf[(size_t)(r * t.cols + c)] = (2.f * hash_uniform(seed, (uint64_t)ti, gidx) - 1.f) * lim;
+                }
+        }
+        if ((rc = pvae_set_tensor(e, ti, buf.data(), n))) return rc;
+    }
+    return pvae_reset_optimizer(e);
+}
+
+int pvae_set_lr(pvae_engine* e, float lr) {
+    e->lr_host = lr;
+    HIPCHK(hipMemcpyAsync(&e->st->lr, &e->lr_host, sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+int pvae_get_lr(pvae_engine* e, float* lr) {
+    *lr = e->lr_host;
+    return 0;
+}
+
+int pvae_train_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3) {
+    return full_step(e, rows, n, eps, out3, 0);
+}
+int pvae_eval_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3) {
+    return full_step(e, rows, n, eps, out3, 1);
+}
+int pvae_grad_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3) {
+    return full_step(e, rows, n, eps, out3, 2);
+}
+
+int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const int32_t* val_rows, int32_t n_val,
+                     float* loss, float* val_loss) {
+    int rc;
+    if (e->cfg.world != 1) return set_err(e, -5, "world > 1: use the staged API");
+    if (!e->geno) return set_err(e, -3, "no genotypes loaded (pvae_load_genotypes)");
+    if (n_train <= 0) return set_err(e, -2, "empty training set");
+    const int B = e->cfg.batch_size;
+    const int st_tr = (n_train + B - 1) / B, st_va = n_val > 0 ? (n_val + B - 1) / B : 0;
+    if ((rc = check_rows(e, perm, n_train))) return rc;
+    if (n_val > 0 && (rc = check_rows(e, val_rows, n_val))) return rc;
+    if ((rc = ensure_rows(e, (int64_t)n_train + std::max(n_val, 0)))) return rc;
+    if ((rc = ensure_loss(e, st_tr + st_va))) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_rows, perm, (size_t)n_train * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    if (n_val > 0)
+        HIPCHK(hipMemcpyAsync(e->d_rows + n_train, val_rows, (size_t)n_val * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    for (int phase = 0; phase < 2; ++phase) {
+        const int steps = phase == 0 ? st_tr : st_va;
+        if (!steps) continue;
+        int nt = phase == 0 ? n_train : n_val;
+        HIPCHK(hipMemcpyAsync(e->d_ntotal, &nt, sizeof(int), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));  // nt is a stack variable
+        const int base = phase == 0 ? 0 : n_train;
+        for (int s = 0; s < steps; ++s) {
+            hipLaunchKernelGGL(pvk_step_begin, dim3(1), dim3(64), 0, e->stream, e->st, (const int*)e->d_ntotal, 0, B, s, phase == 0 ? 1 : 0,
+                               e->adam.b1, e->adam.b2);
+            hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, 32 * e->K, e->cfg.seed, e->d_counter);
+            if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
+            if ((rc = stage_a(e, base + s * B, true))) return rc;
+            if ((rc = stage_b(e, phase == 0 ? 0 : 1))) return rc;
+            if ((rc = stage_c(e, phase == 0 ? 0 : 1, e->d_loss + 3 * ((phase == 0 ? 0 : st_tr) + s)))) return rc;
+        }
+    }
+    std::vector<float> hl((size_t)(st_tr + st_va) * 3);
+    HIPCHK(hipMemcpyAsync(hl.data(), e->d_loss, hl.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    // K9: plain mean of the per-batch scalars (the short last batch counts equally)
+    double a = 0, b = 0;
+    for (int s = 0; s < st_tr; ++s) a += hl[(size_t)s * 3];
+    for (int s = 0; s < st_va; ++s) b += hl[(size_t)(st_tr + s) * 3];
+    if (loss) *loss = (float)(a / st_tr);
+    if (val_loss) *val_loss = st_va ? (float)(b / st_va) : NAN;
+    return 0;
+}
+
+int pvae_stage_encode(pvae_engine* e, int32_t n, float* z_mean, float* z_log_var, float* z) {
+    int rc;
+    if (n <= 0 || n > 32) return set_err(e, -2, "encode batch of %d rows", n);
+    if ((rc = narrow_encoder(e))) return rc;
+    std::vector<float> ho((size_t)32 * e->Kh), zz((size_t)32 * e->Kz);
+    HIPCHK(hipMemcpyAsync(ho.data(), e->headout, ho.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(zz.data(), e->z, zz.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int b = 0; b < n; ++b)
+        for (int k = 0; k < e->K; ++k) {
+            if (z_mean) z_mean[b * e->K + k] = ho[(size_t)b * e->Kh + k];
+            if (z_log_var) z_log_var[b * e->K + k] = ho[(size_t)b * e->Kh + e->K + k];
+            if (z) z[b * e->K + k] = zz[(size_t)b * e->Kz + k];
+        }
+    return 0;
+}
+
+int pvae_encode(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* z_mean, float* z_log_var,
+                float* z) {
+    int rc;
+    if (e->cfg.world != 1) return set_err(e, -5, "world > 1: use pvae_stage_a + all-reduce + pvae_stage_encode");
+    const int B = 32;
+    for (int i0 = 0; i0 < n; i0 += B) {
+        const int nb = std::min(B, n - i0);
+        const int save = e->cfg.batch_size;
+        e->cfg.batch_size = 32;  // predict batches are independent of the training batch size
+        rc = begin_batch(e, rows + i0, nb, eps ? eps + (size_t)i0 * e->K : nullptr, false);
+        e->cfg.batch_size = save;
+        if (rc) return rc;
+        if ((rc = stage_a(e, 0, false))) return rc;
+        if ((rc = pvae_stage_encode(e, nb, z_mean ? z_mean + (size_t)i0 * e->K : nullptr,
+                                    z_log_var ? z_log_var + (size_t)i0 * e->K : nullptr, z ? z + (size_t)i0 * e->K : nullptr)))
+            return rc;
+    }
+    return 0;
+}
+
+int pvae_decode(pvae_engine* e, const float* z, int32_t n, float* probs) {
+    (void)z; (void)n; (void)probs;
+    return set_err(e, -7, "pvae_decode: not built yet (SURVEY 8f row 3)");
+}
+
+int pvae_snapshot_best(pvae_engine* e) {
+    int rc = 0;
+    for_each_buf(e, [&](Buf3& b) {
+        if (rc) return;
+        if (!b.best && hipMalloc(&b.best, b.n * 4) != hipSuccess) { rc = -10; return; }
+        if (hipMemcpyAsync(b.best, b.w, b.n * 4, hipMemcpyDeviceToDevice, e->stream) != hipSuccess) rc = -10;
+    });
+    if (rc) return set_err(e, rc, "snapshot failed: %s", hipGetErrorString(hipGetLastError()));
+    e->has_best = true;
+    return 0;
+}
+
+int pvae_restore_best(pvae_engine* e) {
+    if (!e->has_best) return set_err(e, -6, "no snapshot taken");
+    int rc = 0;
+    for_each_buf(e, [&](Buf3& b) {
+        if (hipMemcpyAsync(b.w, b.best, b.n * 4, hipMemcpyDeviceToDevice, e->stream) != hipSuccess) rc = -10;
+    });
+    if (rc) return set_err(e, rc, "restore failed");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int pvae_exchange_buffer(pvae_engine* e, int which, void** device_ptr, int64_t* n_floats) {
+    if (which == 0) { *device_ptr = e->P; *n_floats = 32 * e->Wp; return 0; }
+    if (which == 1) { *device_ptr = e->xch1; *n_floats = 32 * e->Wp + 32; return 0; }
+    return set_err(e, -2, "exchange buffer %d", which);
+}
+
+int pvae_stage_a(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, int mode) {
+    int rc;
+    if (mode == 3) {
+        const int save = e->cfg.batch_size;
+        e->cfg.batch_size = 32;
+        rc = begin_batch(e, rows, n, eps, false);
+        e->cfg.batch_size = save;
+    } else {
+        rc = begin_batch(e, rows, n, eps, mode == 0);
+    }
+    if (rc) return rc;
+    return stage_a(e, 0, mode != 3);
+}
+int pvae_stage_b(pvae_engine* e, int mode) { return stage_b(e, mode); }
+int pvae_stage_c(pvae_engine* e, int mode, float* out3) {
+    int rc;
+    if ((rc = ensure_loss(e, 1))) return rc;
+    if ((rc = stage_c(e, mode, e->d_loss))) return rc;
+    return fetch_out3(e, out3);
+}
+
+int pvae_set_timing(pvae_engine* e, int enabled) {
+    flush_timing(e);
+    e->timing = enabled != 0;
+    for (int i = 0; i < C_NCAT; ++i) { e->cat_ms[i] = 0; e->cat_n[i] = 0; }
+    return 0;
+}
+int pvae_get_timing(pvae_engine* e, const char* name, float* ms_total, int64_t* launches) {
+    flush_timing(e);
+    for (int i = 0; i < C_NCAT; ++i)
+        if (!strcmp(name, kCatNames[i])) {
+            *ms_total = (float)e->cat_ms[i];
+            *launches = e->cat_n[i];
+            return 0;
+        }
+    return set_err(e, -2, "unknown timing category %s", name);
+}
+
+}  // extern "C"

@@ -1,0 +1,739 @@
+// pvae_kernels.h -- hand-written gfx950 (CDNA4, MI355X) kernels for the popVAE training hot path.
+//
+// Everything here is fp32 and uses the exact f32-input matrix instruction v_mfma_f32_32x32x2_f32
+// (bitwise a k-ordered fmaf chain), so results meet the 1e-4 fp32 parity bar against the oracle.
+//
+// Geometry shared by all kernels
+//   * a batch tile is 32 samples (rows b = 0..31; rows >= nrows are padding and masked out);
+//   * the SNP axis is cut into blocks of 32 SNPs ("blk"); widths are padded to a multiple of 32 and cut
+//     into 32-wide "wb" blocks; a wave works on a *subtile* = one SNP block x NWB width blocks (NWB <= 4,
+//     i.e. <= 128 units); wider layers are split into ngrp = Wp/128 groups of 128 units;
+//   * MFMA 32x32x2 lane maps (lane = 32*h + c):  A[i = c][k = h],  B[k = h][j = c],
+//     C/D reg r <-> row ROW(r,h) = (r&3) + 8*(r>>2) + 4*h, col c.
+//   * the two wide weight matrices (and their Adam moments) are stored in HBM in *fragment-native*
+//     order so that one dwordx4 load per lane per 4 accumulator registers streams a subtile with
+//     perfectly coalesced 1 KiB wave accesses:
+//        float index of element (blk, grp, wbl, r, lane) =
+//            ((blk*ngrp + grp)*NWB + wbl)*1024 + ((r>>2)*64 + lane)*4 + (r&3)
+//     encoder W1 (Keras [L][W]):  (row ROW(r,h) -> SNP blk*32+ROW, col c -> unit (grp*NWB+wbl)*32 + c)
+//     decoder V  (Keras [W][L]):  (row ROW(r,h) -> unit (grp*NWB+wbl)*32 + ROW, col c -> SNP blk*32 + c)
+//   * genotypes: resident matrix packed 2 bits per call, sample-major rows (code = derived count,
+//     value = code/2, SNP l at bits 2*(l%4) of byte l/4 -> one little-endian u64 per (sample, blk));
+//     per batch a transposed copy Xt[blk*32 + l] = u64 with sample b's code at bits 2b.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PV_ROW(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))
+
+enum { PV_ACT_LINEAR = 0, PV_ACT_ELU = 1 };
+enum { PV_MODE_TRAIN = 0, PV_MODE_GRAD = 1 };
+
+struct PvStep {  // device-resident per-step scalars (graph-replay friendly)
+    int t;        // Adam iteration (1-based after pvk_step_begin)
+    float lr;     // float32 learning rate variable (ReduceLROnPlateau mutates it)
+    float alpha;  // lr * sqrt(1 - b2^t) / (1 - b1^t)
+    int nrows;    // valid rows of the current batch tile
+    float inv_b;  // 1 / nrows
+    int step_in_epoch;
+};
+
+struct PvAdam {
+    float b1, b2, eps;
+};
+
+__device__ __forceinline__ float pv_elu(float x) { return x > 0.f ? x : expm1f(x); }
+// derivative of ELU expressed through its output y (alpha = 1): y > 0 ? 1 : y + 1
+__device__ __forceinline__ float pv_elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
+
+__device__ __forceinline__ void pv_adam(float& w, float& m, float& v, float g, float alpha, const PvAdam& A) {
+    m += (g - m) * (1.f - A.b1);
+    v += (g * g - v) * (1.f - A.b2);
+    w -= (m * alpha) / (sqrtf(v) + A.eps);
+}
+
+// code(ROW(r,h)) of a 64-bit word holding 32 2-bit codes, after pre-shifting by 8*h bits
+__device__ __forceinline__ float pv_code(uint32_t lo, uint32_t hi, int r) {
+    const uint32_t w = (r >> 3) ? hi : lo;
+    const int sh = 2 * (r & 3) + 16 * ((r >> 2) & 1);
+    return (float)((w >> sh) & 3u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-step scalars
+// ---------------------------------------------------------------------------------------------
+__global__ void pvk_step_begin(PvStep* st, const int* __restrict__ n_total_ptr, int n_total_val, int batch, int step,
+                               int train, float b1, float b2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int remaining = (n_total_ptr ? *n_total_ptr : n_total_val) - step * batch;
+        int nrows = remaining < batch ? remaining : batch;
+        if (nrows < 0) nrows = 0;
+        st->nrows = nrows;
+        st->inv_b = nrows > 0 ? 1.f / (float)nrows : 0.f;
+        st->step_in_epoch = step;
+        if (train) {
+            int t = st->t + 1;
+            st->t = t;
+            // Keras: alpha = lr * sqrt(1 - beta_2^t) / (1 - beta_1^t), evaluated in float32
+            float b1p = powf(b1, (float)t), b2p = powf(b2, (float)t);
+            st->alpha = st->lr * sqrtf(1.f - b2p) / (1.f - b1p);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batch gather + 2-bit transpose: Xt[l] (u64, sample b at bits 2b) from the resident packed matrix.
+// One wave handles two SNP blocks (lanes 0-31 / 32-63 = sample b of block 2p / 2p+1).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pvk_gather_transpose(const uint8_t* __restrict__ geno, int64_t row_bytes,
+                                                            const int* __restrict__ rows, const PvStep* st,
+                                                            int row_offset, int nblk, uint64_t* __restrict__ Xt) {
+    __shared__ uint64_t sm[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = lane & 31, half = lane >> 5;
+    const int nrows = st->nrows;
+    const int pair = blockIdx.x * 4 + wave;
+    const int blk = pair * 2 + half;
+    uint64_t w = 0;
+    if (blk < nblk && b < nrows) {
+        const int64_t row = rows[row_offset + b];
+        w = *reinterpret_cast<const uint64_t*>(geno + row * row_bytes + (int64_t)blk * 8);
+    }
+    sm[wave][lane] = w;
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0); wave-private LDS row, no barrier needed
+    __builtin_amdgcn_wave_barrier();
+    // lane (l = lane&31, half) assembles SNP l of block `blk`: bits 2l..2l+1 of each sample's word
+    uint64_t out = 0;
+    const int sh = 2 * b;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const uint64_t x = sm[wave][half * 32 + s];
+        out |= ((x >> sh) & 3ull) << (2 * s);
+    }
+    if (blk < nblk) Xt[(int64_t)blk * 32 + b] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wide encoder forward: partial[b][u] = sum_l code(b,l) * W1[l][u] over this wave's SNP blocks.
+// grid = nwg workgroups of 4 waves; global wave gw owns group grp = gw % ngrp and a contiguous chunk
+// of SNP blocks.  Per-wave partials are written to part[gw][r-major fragment] and reduced in fixed
+// order by pvk_enc_reduce (deterministic split-K).
+// ---------------------------------------------------------------------------------------------
+template <int NWB>
+__global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1, const uint8_t* __restrict__ geno,
+                                                   int64_t row_bytes, const int* __restrict__ rows,
+                                                   const PvStep* st, int row_offset, int nblk, int ngrp,
+                                                   float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int grp = gw % ngrp, slot = gw / ngrp, nslots = nwaves / ngrp;
+    const int per = (nblk + nslots - 1) / nslots;
+    const int blk0 = slot * per;
+    int blk1 = blk0 + per;
+    if (blk1 > nblk) blk1 = nblk;
+    const int nrows = st->nrows;
+    const uint8_t* xrow = nullptr;
+    if (c < nrows) xrow = geno + (int64_t)rows[row_offset + c] * row_bytes;
+
+    f32x16 acc[NWB];
+#pragma unroll
+    for (int w = 0; w < NWB; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[w][r] = 0.f;
+
+    for (int blk = blk0; blk < blk1; ++blk) {
+        const f32x4* tile = reinterpret_cast<const f32x4*>(W1) + ((int64_t)blk * ngrp + grp) * (NWB * 256);
+        f32x4 wv[NWB][4];
+#pragma unroll
+        for (int w = 0; w < NWB; ++w)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv[w][q] = __builtin_nontemporal_load(tile + (w * 4 + q) * 64 + lane);
+        uint64_t xw = 0;
+        if (xrow) xw = *reinterpret_cast<const uint64_t*>(xrow + (int64_t)blk * 8);
+        xw >>= (8 * h);
+        const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a = pv_code(lo, hi, r);
+#pragma unroll
+            for (int w = 0; w < NWB; ++w)
+                acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wv[w][r >> 2][r & 3], acc[w], 0, 0, 0);
+        }
+    }
+    // part layout: [gw][w][r][lane]  (row b = ROW(r,h), unit = (grp*NWB + w)*32 + c)
+    float* p = part + (int64_t)gw * (NWB * 1024);
+#pragma unroll
+    for (int w = 0; w < NWB; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[(w * 16 + r) * 64 + lane] = acc[w][r];
+}
+
+// P[b][u] = 0.5 * sum over waves (fixed order) ; one thread per (w, r, lane) element of a group.
+template <int NWB>
+__global__ __launch_bounds__(256) void pvk_enc_reduce(const float* __restrict__ part, int nwaves, int ngrp, int ldp,
+                                                      float* __restrict__ P) {
+    const int e = blockIdx.x * 256 + threadIdx.x;  // element inside one group fragment
+    const int grp = blockIdx.y;
+    if (e >= NWB * 1024) return;
+    float s = 0.f;
+    for (int gw = grp; gw < nwaves; gw += ngrp) s += part[(int64_t)gw * (NWB * 1024) + e];
+    const int w = e >> 10, r = (e >> 6) & 15, lane = e & 63;
+    const int b = PV_ROW(r, lane >> 5), u = (grp * NWB + w) * 32 + (lane & 31);
+    P[b * ldp + u] = 0.5f * s;
+}
+
+// h = act(P + bias)  (first encoder layer epilogue; after the SNP-shard all-reduce when world > 1)
+__global__ void pvk_bias_act(const float* __restrict__ P, const float* __restrict__ bias, int n, int act,
+                             float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 32 * n) return;
+    float x = P[i] + bias[i % n];
+    out[i] = act == PV_ACT_ELU ? pv_elu(x) : x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Narrow dense layer forward: out[32][N] = act(in[32][K] * Wt[K][N] + bias).  grid = N/32 workgroups,
+// 4 waves split the K range; fixed-order LDS reduce.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pvk_dense_fwd(const float* __restrict__ in, int K, const float* __restrict__ Wt,
+                                                     const float* __restrict__ bias, int N, int act,
+                                                     float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* in_s = smem;                  // [32][K+1]
+    float* red = smem + 32 * (K + 1);    // [4][16][64]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    for (int i = tid; i < 32 * K; i += 256) in_s[(i / K) * (K + 1) + (i % K)] = in[i];
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int kper = K / 4;
+    for (int k = wave * kper; k < (wave + 1) * kper; k += 2) {
+        const float a = in_s[c * (K + 1) + k + h];
+        const float b = Wt[(int64_t)(k + h) * N + n0 + c];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+        const float s = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+        const int r = e >> 6, l = e & 63;
+        const int b = PV_ROW(r, l >> 5), n = n0 + (l & 31);
+        const float x = s + bias[n];
+        out[b * N + n] = act == PV_ACT_ELU ? pv_elu(x) : x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Narrow dense layer backward + Adam.  grid = K/32 workgroups (one per 32 input units = 32 rows of Wt).
+//   dpre = dY * act'(Y);  dIn[:, k-block] = dpre * Wt[k-block,:]^T (pre-update weights);
+//   dWt[k-block,:] = in[:, k-block]^T * dpre -> Adam;  workgroup 0 also does the bias.
+// MODE_GRAD writes raw gradients to gW/gB instead of updating.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void pvk_dense_bwd(const float* __restrict__ in, int K, float* __restrict__ Wt,
+                                                     float* __restrict__ mW, float* __restrict__ vW,
+                                                     float* __restrict__ bias, float* __restrict__ mB,
+                                                     float* __restrict__ vB, int N, int act,
+                                                     const float* __restrict__ Y, const float* __restrict__ dY,
+                                                     float* __restrict__ dIn, const PvStep* st, PvAdam adam) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int ld = N + 1;
+    float* dp_s = smem;             // [32][N+1]
+    float* w_s = smem + 32 * ld;    // [32][N+1]
+    float* red = w_s + 32 * ld;     // [4][16][64]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int k0 = blockIdx.x * 32;
+    const int nrows = st->nrows;
+    const float alpha = st->alpha;
+    for (int i = tid; i < 32 * N; i += 256) {
+        const int b = i / N, n = i % N;
+        float d = b < nrows ? dY[i] : 0.f;
+        if (act == PV_ACT_ELU) d *= pv_elu_grad_from_out(Y[i]);
+        dp_s[b * ld + n] = d;
+        w_s[b * ld + n] = Wt[(int64_t)(k0 + b) * N + n];
+    }
+    __syncthreads();
+    if (dIn) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int nper = N / 4;  // N is a multiple of 32
+        for (int n = wave * nper; n < (wave + 1) * nper; n += 2) {
+            const float a = dp_s[c * ld + n + h];   // A[i=b][k=n]
+            const float b = w_s[c * ld + n + h];    // B[k=n][j=k_loc]
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+        __syncthreads();
+        for (int e = tid; e < 1024; e += 256) {
+            const float s = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+            const int r = e >> 6, l = e & 63;
+            dIn[PV_ROW(r, l >> 5) * K + k0 + (l & 31)] = s;
+        }
+    }
+    // dWt fragments: M = k_loc, N = n, K = b
+    for (int nb = wave; nb < N / 32; nb += 4) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float a = in[(2 * s + h) * K + k0 + c];
+            const float b = dp_s[(2 * s + h) * ld + nb * 32 + c];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kl = PV_ROW(r, h);
+            const int64_t idx = (int64_t)(k0 + kl) * N + nb * 32 + c;
+            if (MODE == PV_MODE_GRAD) {
+                mW[idx] = acc[r];
+            } else {
+                float w = w_s[kl * ld + nb * 32 + c], m = mW[idx], v = vW[idx];
+                pv_adam(w, m, v, acc[r], alpha, adam);
+                Wt[idx] = w;
+                mW[idx] = m;
+                vW[idx] = v;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && bias) {
+        for (int n = tid; n < N; n += 256) {
+            float g = 0.f;
+            for (int b = 0; b < 32; ++b) g += dp_s[b * ld + n];
+            if (MODE == PV_MODE_GRAD) {
+                mB[n] = g;
+            } else {
+                float w = bias[n], m = mB[n], v = vB[n];
+                pv_adam(w, m, v, g, alpha, adam);
+                bias[n] = w;
+                mB[n] = m;
+                vB[n] = v;
+            }
+        }
+    }
+}
+
+// dpre = dY * act'(Y) (rows >= nrows zeroed) written out, plus bias gradient / Adam.  Used for the wide
+// first encoder layer whose weight gradient is formed by pvk_enc_bwd.
+template <int MODE>
+__global__ void pvk_bias_bwd(const float* __restrict__ Y, const float* __restrict__ dY, int N, int act,
+                             float* __restrict__ dpre, float* __restrict__ bias, float* __restrict__ mB,
+                             float* __restrict__ vB, const PvStep* st, PvAdam adam) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int nrows = st->nrows;
+    float g = 0.f;
+    for (int b = 0; b < 32; ++b) {
+        float d = b < nrows ? dY[b * N + n] : 0.f;
+        if (act == PV_ACT_ELU) d *= pv_elu_grad_from_out(Y[b * N + n]);
+        dpre[b * N + n] = d;
+        g += d;
+    }
+    if (MODE == PV_MODE_GRAD) {
+        mB[n] = g;
+    } else {
+        float w = bias[n], m = mB[n], v = vB[n];
+        pv_adam(w, m, v, g, st->alpha, adam);
+        bias[n] = w;
+        mB[n] = m;
+        vB[n] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reparameterisation + KL (popvae.py:384-389, 419-421).  heads[32][ldh]: cols [0,K) = z_mean,
+// [K,2K) = z_log_var.  z[32][ldz] (padding columns zero).  kl[b] = -0.5*sum(1 + s - mu^2 - e^s).
+// ---------------------------------------------------------------------------------------------
+__global__ void pvk_reparam(const float* __restrict__ heads, int ldh, int K, const float* __restrict__ eps,
+                            float* __restrict__ z, int ldz, float* __restrict__ kl) {
+    const int b = threadIdx.x;
+    if (b >= 32) return;
+    float acc = 0.f;
+    for (int k = 0; k < ldz; ++k) {
+        float zz = 0.f;
+        if (k < K) {
+            const float mu = heads[b * ldh + k], s = heads[b * ldh + K + k];
+            const float es = expf(s);
+            zz = mu + es * eps[b * K + k];  // NOTE exp(s), not exp(s/2): popvae.py:389
+            acc += 1.f + s - mu * mu - es;
+        }
+        z[b * ldz + k] = zz;
+    }
+    kl[b] = -0.5f * acc;
+}
+
+// d heads from dz: dmu = dz + mu/B ; ds = dz*eps*e^s + 0.5*(e^s - 1)/B ; rows >= nrows -> 0
+__global__ void pvk_reparam_bwd(const float* __restrict__ heads, int ldh, int K, const float* __restrict__ eps,
+                                const float* __restrict__ dz, int ldz, float* __restrict__ dheads,
+                                const PvStep* st) {
+    const int b = threadIdx.x;
+    if (b >= 32) return;
+    const bool valid = b < st->nrows;
+    const float ib = st->inv_b;
+    for (int k = 0; k < ldh; ++k) dheads[b * ldh + k] = 0.f;
+    if (!valid) return;
+    for (int k = 0; k < K; ++k) {
+        const float mu = heads[b * ldh + k], s = heads[b * ldh + K + k];
+        const float es = expf(s), d = dz[b * ldz + k];
+        dheads[b * ldh + k] = d + mu * ib;
+        dheads[b * ldh + K + k] = d * eps[b * K + k] * es + 0.5f * (es - 1.f) * ib;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wide decoder, fused: logits -> sigmoid -> BCE (+ loss) -> dlogits -> dV (+Adam in place), dbias
+// (+Adam), dg partials.  One wave per subtile (NGRP == 1: the whole width in one wave).
+// LDS (dynamic): g_s [32][ldg] shared; per wave: vt [2][32][33] (V^T staging) and dt [32][33] (da^T).
+// Outputs per workgroup: dgpart[wg][32][Wp] and losspart[wg] (summed BCE of this workgroup's SNPs).
+// TRAIN: 0 = evaluation (loss only), 1 = training.
+// ---------------------------------------------------------------------------------------------
+template <int NWB, int TRAIN, int MODE>
+__global__ __launch_bounds__(256, 2) void pvk_dec(float* __restrict__ V, float* __restrict__ mV, float* __restrict__ vV,
+                                                  float* __restrict__ cb, float* __restrict__ mC, float* __restrict__ vC,
+                                                  const float* __restrict__ g, const uint64_t* __restrict__ Xt,
+                                                  int nblk, int L, const PvStep* st, PvAdam adam,
+                                                  float* __restrict__ dgpart, float* __restrict__ losspart) {
+    constexpr int WP = NWB * 32;
+    constexpr int LDG = WP + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* g_s = smem;                                   // [32][LDG]
+    float* wave_s = smem + 32 * LDG + (threadIdx.x >> 6) * (3 * 32 * 33);
+    float* vt = wave_s;                                  // [2][32][33]
+    float* dt = wave_s + 2 * 32 * 33;                    // [32][33]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int gw = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    const int per = (nblk + nwaves - 1) / nwaves;
+    const int blk0 = gw * per;
+    int blk1 = blk0 + per;
+    if (blk1 > nblk) blk1 = nblk;
+    const int nrows = st->nrows;
+    const float inv_b = st->inv_b, alpha = st->alpha;
+
+    for (int i = tid; i < 32 * WP; i += 256) g_s[(i / WP) * LDG + (i % WP)] = g[i];
+    __syncthreads();
+
+    f32x16 dg[NWB];
+    float lossacc = 0.f;  // only the batch total enters the loss (popvae.py:423)
+    if (TRAIN) {
+#pragma unroll
+        for (int w = 0; w < NWB; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dg[w][r] = 0.f;
+    }
+
+    for (int blk = blk0; blk < blk1; ++blk) {
+        // keep the (loop-invariant) g operand reads inside the loop: hoisting them costs 128 VGPRs
+        asm volatile("" ::: "memory");
+        const int64_t tbase = (int64_t)blk * (NWB * 256);  // in f32x4 units
+        f32x4* tV = reinterpret_cast<f32x4*>(V) + tbase;
+        f32x4 vv[NWB][4];
+#pragma unroll
+        for (int w = 0; w < NWB; ++w)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vv[w][q] = tV[(w * 4 + q) * 64 + lane];
+        const int l = blk * 32 + c;
+        const bool lvalid = l < L;
+        const float bias = cb[l];
+        uint64_t xw = Xt[l] >> (8 * h);
+        const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
+
+        // (1) logits a[b][l] : M = b, N = l, K = unit.  A = g[b][unit], B = V fragment register.
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWB; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ga = g_s[c * LDG + w * 32 + PV_ROW(r, h)];
+                a = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, vv[w][r >> 2][r & 3], a, 0, 0, 0);
+            }
+        // (2) sigmoid / BCE-from-logits / dlogits ; reg r <-> sample b = ROW(r,h), lane <-> SNP l
+        float dbias = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = PV_ROW(r, h);
+            const float x = 0.5f * pv_code(lo, hi, r);
+            const float z = a[r] + bias;
+            const float e = __expf(-fabsf(z));                 // exp(-|z|)
+            const float bce = fmaxf(z, 0.f) - z * x + log1pf(e);
+            const float inv = 1.f / (1.f + e);
+            const float p = z >= 0.f ? inv : e * inv;            // sigmoid(z)
+            const bool ok = lvalid && (b < nrows);
+            lossacc += ok ? bce : 0.f;
+            const float d = ok ? (p - x) * inv_b : 0.f;
+            a[r] = d;
+            dbias += d;
+        }
+        if (TRAIN) {
+            // bias: sum over the 32 samples = 16 regs + the other half-wave
+            dbias += __shfl_xor(dbias, 32);
+            if (h == 0 && lvalid) {
+                if (MODE == PV_MODE_GRAD) {
+                    mC[l] = dbias;
+                } else {
+                    float w_ = bias, m_ = mC[l], v_ = vC[l];
+                    pv_adam(w_, m_, v_, dbias, alpha, adam);
+                    cb[l] = w_;
+                    mC[l] = m_;
+                    vC[l] = v_;
+                }
+            }
+            // da^T into LDS for product (3): dt[b][l_loc]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dt[PV_ROW(r, h) * 33 + c] = a[r];
+            // (3) dg[b][unit] += sum_l da[b][l] * V[unit][l] : M = b, N = unit, K = l
+            //     B operand needs V^T (unit on the lane): stage each 32x32 block through LDS.
+#pragma unroll
+            for (int w = 0; w < NWB; ++w) {
+                float* vts = vt + (w & 1) * (32 * 33);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vts[PV_ROW(r, h) * 33 + c] = vv[w][r >> 2][r & 3];  // [unit_loc][l_loc]
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float av = dt[c * 33 + PV_ROW(r, h)];   // A[i=b][k=l]
+                    const float bv = vts[c * 33 + PV_ROW(r, h)];  // B[k=l][j=unit_loc]
+                    dg[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, dg[w], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // (4) dV[unit][l] = sum_b g[b][unit] * da[b][l] : M = unit, N = l, K = b ; then Adam
+            f32x4* tM = reinterpret_cast<f32x4*>(mV) + tbase;
+            f32x4* tVv = reinterpret_cast<f32x4*>(vV) + tbase;
+#pragma unroll
+            for (int w = 0; w < NWB; ++w) {
+                f32x16 dv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dv[r] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ga = g_s[PV_ROW(r, h) * LDG + w * 32 + c];  // A[i=unit_loc][k=b]
+                    dv = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, a[r], dv, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int off = (w * 4 + q) * 64 + lane;
+                    if (MODE == PV_MODE_GRAD) {
+                        f32x4 gq = {dv[q * 4 + 0], dv[q * 4 + 1], dv[q * 4 + 2], dv[q * 4 + 3]};
+                        tM[off] = gq;
+                    } else {
+                        f32x4 wq = vv[w][q], mq = tM[off], vq = tVv[off];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float w_ = wq[e], m_ = mq[e], v_ = vq[e];
+                            pv_adam(w_, m_, v_, dv[q * 4 + e], alpha, adam);
+                            wq[e] = w_;
+                            mq[e] = m_;
+                            vq[e] = v_;
+                        }
+                        tV[off] = wq;
+                        tM[off] = mq;
+                        tVv[off] = vq;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // ---- per-workgroup reductions (fixed order) ----
+    __syncthreads();  // everyone done with g_s / wave staging
+    float* red = smem;  // reuse: [4][NWB*16][64] for dg, then [4][32] loss
+    // loss: fixed-order butterfly over the wave, then over the 4 waves
+    lossacc += __shfl_xor(lossacc, 1);
+    lossacc += __shfl_xor(lossacc, 2);
+    lossacc += __shfl_xor(lossacc, 4);
+    lossacc += __shfl_xor(lossacc, 8);
+    lossacc += __shfl_xor(lossacc, 16);
+    lossacc += __shfl_xor(lossacc, 32);
+    float* lred = red + 4 * NWB * 1024;
+    if (lane == 0) lred[wave] = lossacc;
+    if (TRAIN) {
+#pragma unroll
+        for (int w = 0; w < NWB; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave * NWB + w) * 16 + r) * 64 + lane] = dg[w][r];
+    }
+    __syncthreads();
+    if (tid == 0) losspart[blockIdx.x] = ((lred[0] + lred[1]) + lred[2]) + lred[3];
+    if (TRAIN) {
+        for (int e = tid; e < NWB * 1024; e += 256) {
+            const float s = ((red[e] + red[NWB * 1024 + e]) + red[2 * NWB * 1024 + e]) + red[3 * NWB * 1024 + e];
+            const int w = e >> 10, r = (e >> 6) & 15, ln = e & 63;
+            dgpart[(int64_t)blockIdx.x * (32 * WP) + PV_ROW(r, ln >> 5) * WP + w * 32 + (ln & 31)] = s;
+        }
+    }
+}
+
+// dgD[b][u] = sum_wg dgpart (fixed order) ; recon[0] = sum_wg losspart (recon[1..31] = 0).
+// grid covers 32*Wp + 32 elements.
+__global__ void pvk_dec_reduce(const float* __restrict__ dgpart, const float* __restrict__ losspart, int nwg, int n_dg,
+                               float* __restrict__ dg, float* __restrict__ recon) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_dg) {
+        float s = 0.f;
+        for (int w = 0; w < nwg; ++w) s += dgpart[(int64_t)w * n_dg + i];
+        dg[i] = s;
+    } else if (i < n_dg + 32) {
+        const int b = i - n_dg;
+        float s = 0.f;
+        if (b == 0)
+            for (int w = 0; w < nwg; ++w) s += losspart[w];
+        recon[b] = s;
+    }
+}
+
+// loss = mean_b(recon + kl) over valid rows (popvae.py:423) -> out[0..2] = loss, mean recon, mean kl
+__global__ void pvk_loss_final(const float* __restrict__ recon, const float* __restrict__ kl, const PvStep* st,
+                               float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        const int n = st->nrows;
+        float sr = recon[0], sk = 0.f;
+        for (int b = 0; b < n; ++b) sk += kl[b];
+        out[0] = (sr + sk) * st->inv_b;
+        out[1] = sr * st->inv_b;
+        out[2] = sk * st->inv_b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wide encoder backward + Adam: dW1[l][u] = 0.5 * sum_b code(b,l) * dpre1[b][u]; M = l, N = u, K = b.
+// One wave per subtile; dpre1 staged once per workgroup in LDS.
+// ---------------------------------------------------------------------------------------------
+template <int NWB, int MODE>
+__global__ __launch_bounds__(256) void pvk_enc_bwd(float* __restrict__ W1, float* __restrict__ mW, float* __restrict__ vW,
+                                                   const float* __restrict__ dpre, int ldp, const uint64_t* __restrict__ Xt,
+                                                   int nblk, int ngrp, const PvStep* st, PvAdam adam) {
+    constexpr int WG_UNITS = NWB * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [ngrp][32][WG_UNITS]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int gw = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    const float alpha = st->alpha;
+    for (int i = tid; i < 32 * ldp; i += 256) {
+        const int b = i / ldp, u = i % ldp;
+        smem[((u / WG_UNITS) * 32 + b) * WG_UNITS + (u % WG_UNITS)] = dpre[i];
+    }
+    __syncthreads();
+    const int64_t ntasks = (int64_t)nblk * ngrp;
+    const int64_t per = (ntasks + nwaves - 1) / nwaves;
+    int64_t t0 = gw * per, t1 = t0 + per;
+    if (t1 > ntasks) t1 = ntasks;
+    for (int64_t t = t0; t < t1; ++t) {
+        const int blk = (int)(t / ngrp), grp = (int)(t % ngrp);
+        const float* dp = smem + grp * 32 * WG_UNITS;
+        uint64_t xw = Xt[blk * 32 + c] >> (8 * h);
+        const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
+        float xa[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xa[r] = pv_code(lo, hi, r);
+        f32x4* tW = reinterpret_cast<f32x4*>(W1) + t * (NWB * 256);
+        f32x4* tM = reinterpret_cast<f32x4*>(mW) + t * (NWB * 256);
+        f32x4* tV = reinterpret_cast<f32x4*>(vW) + t * (NWB * 256);
+#pragma unroll
+        for (int w = 0; w < NWB; ++w) {
+            f32x16 dw;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dw[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bv = dp[PV_ROW(r, h) * WG_UNITS + w * 32 + c];  // B[k=b][j=unit]
+                dw = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[r], bv, dw, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int off = (w * 4 + q) * 64 + lane;
+                if (MODE == PV_MODE_GRAD) {
+                    f32x4 gq = {0.5f * dw[q * 4 + 0], 0.5f * dw[q * 4 + 1], 0.5f * dw[q * 4 + 2], 0.5f * dw[q * 4 + 3]};
+                    tM[off] = gq;
+                } else {
+                    f32x4 wq = tW[off], mq = tM[off], vq = tV[off];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float w_ = wq[e], m_ = mq[e], v_ = vq[e];
+                        pv_adam(w_, m_, v_, 0.5f * dw[q * 4 + e], alpha, adam);
+                        wq[e] = w_;
+                        mq[e] = m_;
+                        vq[e] = v_;
+                    }
+                    tW[off] = wq;
+                    tM[off] = mq;
+                    tV[off] = vq;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// N(0,1) draws for the reparameterisation (K3: TF's Philox stream is not reproducible outside TF, any
+// standard-normal generator is admissible).  Philox4x32-10 + Box-Muller, counter = (call, index).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pv_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                          uint32_t out[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ void pvk_gen_eps(float* __restrict__ eps, int n, uint64_t seed, uint64_t* __restrict__ counter) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t call = *counter;
+    if (i < n) {
+        uint32_t o[4];
+        pv_philox((uint32_t)i, 0u, (uint32_t)call, (uint32_t)(call >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        eps[i] = sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    }
+    __syncthreads();
+    if (i == 0) *counter = call + 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Layout conversion between Keras row-major tensors and the fragment-native tiled layout.
+// kind 0: encoder W1 (Keras [L][W]);  kind 1: decoder V (Keras [W][L]).  dir 0: keras->tiled, 1: tiled->keras.
+// One thread per tiled element (padding elements are written as zero on import).
+// ---------------------------------------------------------------------------------------------
+__global__ void pvk_convert_wide(float* __restrict__ tiled, float* __restrict__ keras, int kind, int dir, int64_t L,
+                                 int W, int nblk, int ngrp, int NWB) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)nblk * ngrp * NWB * 1024;
+    if (i >= total) return;
+    const int e = i & 3, lane = (i >> 2) & 63, q = (i >> 8) & 3;
+    const int64_t sub = i >> 10;  // (blk*ngrp + grp)*NWB + wbl
+    const int wbl = sub % NWB;
+    const int grp = (sub / NWB) % ngrp;
+    const int64_t blk = sub / ((int64_t)NWB * ngrp);
+    const int r = q * 4 + e, h = lane >> 5, c = lane & 31;
+    int64_t l;
+    int u;
+    if (kind == 0) {
+        l = blk * 32 + PV_ROW(r, h);
+        u = (grp * NWB + wbl) * 32 + c;
+    } else {
+        u = (grp * NWB + wbl) * 32 + PV_ROW(r, h);
+        l = blk * 32 + c;
+    }
+    const bool inside = l < L && u < W;
+    const int64_t kidx = kind == 0 ? l * W + u : (int64_t)u * L + l;
+    if (dir == 0)
+        tiled[i] = inside ? keras[kidx] : 0.f;
+    else if (inside)
+        keras[kidx] = tiled[i];
+}

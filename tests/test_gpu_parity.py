@@ -1,0 +1,174 @@
+"""HIP path (through the C ABI) vs the oracle on the same seeded inputs.  fp32 tolerance: 1e-4 relative
+(north_star) on loss and on every gradient tensor (relative to the tensor's max |g|)."""
+import numpy as np
+import pytest
+
+from oracle import popvae_oracle as O
+from popvae_amd import engine, prep
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _problem(N, L, W, D, K, seed):
+    g = np.random.default_rng(seed)
+    f = np.clip(g.beta(0.5, 0.5, L), 0.02, 0.98)
+    dc = g.binomial(2, f, size=(N, L)) * 0.5
+    w = O.init_weights(L, W, D, K, seed=seed, dtype=np.float64)
+    for t in w:  # non-zero biases so that bias paths are exercised
+        if t.ndim == 1:
+            t += g.normal(0, 0.05, t.shape)
+    return dc, w
+
+
+def _mk(dc, w, W, D, K, B=32, seed=0):
+    e = engine.Engine(n_snps=dc.shape[1], width=W, depth=D, latent_dim=K, batch_size=B, seed=seed)
+    e.load_genotypes(prep.pack_dc(dc))
+    e.set_weights([x.astype(np.float32) for x in w])
+    return e
+
+
+def _relerr(a, b):
+    s = max(np.abs(b).max(), 1e-30)
+    return np.abs(a - b).max() / s
+
+
+CASES = [
+    # N, L, W, D, K, nrows
+    (40, 64, 32, 2, 2, 32),
+    (40, 1000, 128, 3, 2, 32),
+    (50, 3887, 128, 6, 2, 32),     # pabu-shaped (C1)
+    (50, 3887, 128, 6, 2, 21),     # short last batch (85 % 32 = 21)
+    (40, 777, 64, 3, 3, 7),        # ragged L, W = 64, K = 3
+    (40, 300, 100, 2, 5, 32),      # width padded 100 -> 128
+    (33, 31, 32, 1, 1, 1),         # L < one block, depth 1, single row
+]
+
+
+@pytest.mark.parametrize("N,L,W,D,K,n", CASES)
+def test_loss_and_gradients(N, L, W, D, K, n):
+    dc, w = _problem(N, L, W, D, K, seed=L + W)
+    g = np.random.default_rng(1)
+    rows = g.choice(N, n, replace=False).astype(np.int32)
+    eps = g.normal(size=(n, K))
+    e = _mk(dc, w, W, D, K)
+    w32 = [x.astype(np.float32).astype(np.float64) for x in w]
+    c = O.forward(w32, dc[rows], eps.astype(np.float32).astype(np.float64), D, K)
+    grads = O.backward(w32, c, D, K)
+    loss, recon, kl = e.grad_step(rows, eps)
+    assert abs(loss - c["loss"]) <= RTOL * abs(c["loss"])
+    assert abs(recon - c["recon"].mean()) <= RTOL * abs(c["recon"].mean())
+    assert abs(kl - c["kl"].mean()) <= 1e-3 * abs(c["kl"].mean()) + 1e-5
+    got = e.get_grads()
+    for i, (a, b) in enumerate(zip(got, grads)):
+        assert a.shape == b.shape
+        assert _relerr(a, b) <= RTOL, (i, _relerr(a, b))
+    # eval step gives the same loss and leaves weights alone
+    l2, _, _ = e.eval_step(rows, eps)
+    assert abs(l2 - c["loss"]) <= RTOL * abs(c["loss"])
+    for a, b in zip(e.get_weights(), w):
+        assert np.array_equal(a, b.astype(np.float32))
+    e.close()
+
+
+def test_weight_roundtrip_and_layouts():
+    dc, w = _problem(10, 333, 96, 3, 2, seed=5)
+    e = _mk(dc, w, 96, 3, 2)
+    for a, b in zip(e.get_weights(), w):
+        assert np.array_equal(a, b.astype(np.float32))
+    e.close()
+
+
+@pytest.mark.parametrize("L,W,D", [(1000, 128, 3), (3887, 128, 6)])
+def test_adam_training_steps_match_oracle(L, W, D):
+    """Five fused-Adam train steps (incl. a short batch) vs oracle float64 Keras-Adam."""
+    N, K = 64, 2
+    dc, w = _problem(N, L, W, D, K, seed=11)
+    e = _mk(dc, w, W, D, K)
+    wo = [x.astype(np.float32).astype(np.float64) for x in w]
+    opt = O.KerasAdam(wo)
+    g = np.random.default_rng(2)
+    for step in range(5):
+        n = 32 if step != 3 else 13
+        rows = g.choice(N, n, replace=False).astype(np.int32)
+        eps = g.normal(size=(n, K)).astype(np.float32)
+        lo, _ = O.train_step(wo, opt, dc[rows], eps.astype(np.float64), D, K)
+        lg, _, _ = e.train_step(rows, eps)
+        assert abs(lg - lo) <= RTOL * abs(lo), (step, lg, lo)
+    # Adam's first steps move every weight by ~lr regardless of gradient scale, so compare the UPDATE
+    # (w_after - w_before) relative to lr*steps, plus the moments against the oracle's.
+    for i, (a, b, b0) in enumerate(zip(e.get_weights(), wo, w)):
+        upd_err = np.abs(a.astype(np.float64) - b).max()
+        assert upd_err <= 2e-2 * 5e-3, (i, upd_err)  # 2% of the 5*lr travel
+    for i, (a, b) in enumerate(zip(e.get_moments(0), opt.m)):
+        assert _relerr(a, b) <= 1e-3, ("m", i, _relerr(a, b))
+    for i, (a, b) in enumerate(zip(e.get_moments(1), opt.v)):
+        assert _relerr(a, b) <= 1e-3, ("v", i, _relerr(a, b))
+    e.close()
+
+
+def test_encode_matches_oracle():
+    N, L, W, D, K = 70, 500, 128, 4, 2
+    dc, w = _problem(N, L, W, D, K, seed=3)
+    e = _mk(dc, w, W, D, K)
+    rows = np.arange(N, dtype=np.int32)
+    eps = np.random.default_rng(0).normal(size=(N, K)).astype(np.float32)
+    mu, lv, z = e.encode(rows, eps)
+    w32 = [x.astype(np.float32).astype(np.float64) for x in w]
+    mo, so, zo = O.encode(w32, dc, eps.astype(np.float64), D, K)
+    for a, b in ((mu, mo), (lv, so), (z, zo)):
+        assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
+    e.close()
+
+
+def test_epoch_matches_stepwise_and_learns():
+    N, L, W, D, K = 95, 2000, 128, 3, 2
+    g = np.random.default_rng(0)
+    pop = g.integers(0, 2, N)
+    f = np.clip(g.beta(.5, .5, L)[None] + 0.35 * (pop[:, None] - .5) * g.normal(size=L)[None], .02, .98)
+    dc = g.binomial(2, f) * 0.5
+    w = O.init_weights(L, W, D, K, seed=4, dtype=np.float32)
+    e = _mk(dc, w, W, D, K)
+    train, val = np.arange(85, dtype=np.int32), np.arange(85, 95, dtype=np.int32)
+    first = None
+    for ep in range(12):
+        loss, vloss = e.train_epoch(g.permutation(train).astype(np.int32), val)
+        first = first or loss
+    assert np.isfinite(loss) and np.isfinite(vloss) and loss < 0.9 * first
+    # best-weights snapshot / restore (ModelCheckpoint + load_weights)
+    e.snapshot_best()
+    w_best = e.get_weights()
+    e.train_epoch(train, val)
+    assert not np.array_equal(e.get_weights()[0], w_best[0])
+    e.restore_best()
+    for a, b in zip(e.get_weights(), w_best):
+        assert np.array_equal(a, b)
+    e.close()
+
+
+def test_engine_rng_eps_is_standard_normal():
+    N, L, W, D, K = 64, 64, 32, 2, 2
+    dc, w = _problem(N, L, W, D, K, seed=8)
+    e = _mk(dc, w, W, D, K, seed=123)
+    zs, mus, lvs = [], [], []
+    for _ in range(60):
+        mu, lv, z = e.encode(np.arange(32, dtype=np.int32))
+        zs.append(z), mus.append(mu), lvs.append(lv)
+    eps = (np.concatenate(zs) - np.concatenate(mus)) / np.exp(np.concatenate(lvs))
+    assert abs(eps.mean()) < 0.06 and abs(eps.std() - 1) < 0.06
+    e.close()
+
+
+def test_errors_are_loud():
+    dc, w = _problem(10, 64, 32, 2, 2, seed=1)
+    e = _mk(dc, w, 32, 2, 2)
+    with pytest.raises(RuntimeError):
+        e.train_step(np.array([10], np.int32))       # row out of range
+    with pytest.raises(RuntimeError):
+        e.train_step(np.arange(33, dtype=np.int32) % 10)  # batch too large
+    bad = prep.pack_dc(dc).copy()
+    bad[0, 0] |= 3
+    with pytest.raises(RuntimeError):
+        e.load_genotypes(bad)                         # reserved 'missing' code
+    e.close()
