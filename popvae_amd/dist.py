@@ -1,0 +1,182 @@
+"""SNP-axis sharding of one VAE over the GPUs of a node (one process per GPU, torch.distributed).
+
+The reference has no multi-GPU path (popvae.py:82-89,187 only select a device); this is the layout
+SURVEY.md section 8(e) prescribes: rank r owns a contiguous block of SNP columns -- the matching rows of
+the first encoder kernel, columns of the last decoder kernel, output-bias entries, their Adam slots and
+the same columns of the genotype matrix.  The narrow layers are replicated and computed redundantly.
+Per train step there are exactly two small SUM all-reduces:
+
+  1. partial first-layer sums  X_r . W1_r           [32 x width]        (after stage A)
+  2. partial decoder feedback  dg_D (and BCE sum)   [32 x width + 32]   (after stage B)
+
+All ranks receive bit-identical reduced buffers, so the replicated narrow layers stay bit-identical
+without any gradient all-reduce.  RCCL is reached through torch.distributed (backend "nccl"); "gloo"
+works too (CPU tests, or several ranks sharing one GPU).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .engine import MODE_ENCODE, MODE_EVAL, MODE_GRAD, MODE_TRAIN, Engine
+
+
+def shard_bounds(n_snps, world):
+    """SNP range [lo, hi) per rank; boundaries fall on multiples of 32 SNPs (= 8 packed bytes)."""
+    nblk = (n_snps + 31) // 32
+    per = (nblk + world - 1) // world
+    out = []
+    for r in range(world):
+        lo = min(r * per * 32, n_snps)
+        hi = min((r + 1) * per * 32, n_snps)
+        out.append((lo, hi))
+    return out
+
+
+def shard_packed(packed, n_snps, lo, hi):
+    """Columns [lo, hi) of a packed genotype matrix (lo is a multiple of 32)."""
+    assert lo % 32 == 0
+    nbytes = (hi - lo + 31) // 32 * 8
+    out = np.zeros((packed.shape[0], nbytes), np.uint8)
+    src = packed[:, lo // 4: lo // 4 + nbytes]
+    out[:, :src.shape[1]] = src
+    if (hi - lo) % 4:  # clear codes beyond hi inside the last byte
+        keep = (1 << (2 * ((hi - lo) % 4))) - 1
+        out[:, (hi - lo) // 4] &= keep
+    out[:, (hi - lo + 3) // 4:] = 0
+    return out
+
+
+class _DevArray:
+    """Zero-copy view of an engine-owned device buffer for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 2}
+
+
+class ShardedEngine:
+    """Same host interface as ``Engine`` for a model whose SNP axis is split over ``dist`` ranks."""
+
+    def __init__(self, n_snps, width=128, depth=6, latent_dim=2, batch_size=32, seed=0, device_id=0,
+                 process_group=None, engine_factory=Engine, **adam):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.pg = process_group
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.n_snps_global = int(n_snps)
+        self.bounds = shard_bounds(self.n_snps_global, self.world)
+        self.lo, self.hi = self.bounds[self.rank]
+        if self.hi <= self.lo:
+            raise ValueError(f"rank {self.rank} would own no SNPs ({n_snps} SNPs over {self.world} ranks)")
+        self.latent_dim, self.batch_size = int(latent_dim), int(batch_size)
+        self.eng = engine_factory(n_snps=self.hi - self.lo, width=width, depth=depth, latent_dim=latent_dim,
+                                  batch_size=batch_size, seed=seed, device_id=device_id,
+                                  n_snps_global=self.n_snps_global, snp_offset=self.lo, rank=self.rank,
+                                  world=self.world, **adam)
+        self._bufs = [self._wrap(*self.eng.exchange_buffer(i), device_id) for i in (0, 1)]
+        if hasattr(self.eng, "set_stream") and torch.cuda.is_available():
+            self.eng.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def _wrap(self, ptr, n, device_id):
+        if isinstance(ptr, self._torch.Tensor):  # test doubles hand out CPU tensors directly
+            return ptr
+        return self._torch.as_tensor(_DevArray(ptr, n), device=f"cuda:{device_id}")
+
+    def _allreduce(self, which):
+        if self.world > 1:
+            self._dist.all_reduce(self._bufs[which], op=self._dist.ReduceOp.SUM, group=self.pg)
+
+    # -- data / weights ------------------------------------------------------------------------
+    def load_genotypes(self, packed_full):
+        """``packed_full`` is the whole matrix (every rank slices its own columns)."""
+        self.eng.load_genotypes(shard_packed(np.asarray(packed_full), self.n_snps_global, self.lo, self.hi))
+
+    def load_genotypes_shard(self, packed_shard):
+        self.eng.load_genotypes(packed_shard)
+
+    def init_weights(self, seed):
+        self.eng.init_weights(seed)
+
+    def set_weights(self, weights):
+        """Full (unsharded) Keras-order tensors; the SNP-axis ones are sliced here."""
+        w = list(weights)
+        w[0] = np.ascontiguousarray(w[0][self.lo:self.hi])
+        w[-2] = np.ascontiguousarray(w[-2][:, self.lo:self.hi])
+        w[-1] = np.ascontiguousarray(w[-1][self.lo:self.hi])
+        self.eng.set_weights(w)
+
+    def get_weights_shard(self):
+        return self.eng.get_weights()
+
+    @property
+    def lr(self):
+        return self.eng.lr
+
+    @lr.setter
+    def lr(self, v):
+        self.eng.lr = v
+
+    def snapshot_best(self):
+        self.eng.snapshot_best()
+
+    def restore_best(self):
+        self.eng.restore_best()
+
+    # -- steps ---------------------------------------------------------------------------------
+    def _step(self, rows, eps, mode, want_loss=True):
+        self.eng.stage_a(rows, eps, mode)
+        self._allreduce(0)
+        self.eng.stage_b(mode)
+        self._allreduce(1)
+        return self.eng.stage_c(mode, want_loss)
+
+    def _eps(self, n, eps):
+        """Replicated layers need the SAME noise on every rank.  With eps=None every engine draws from its
+        counter-based generator keyed by (seed, call index): identical seeds + identical call sequences
+        give identical draws on all ranks, with no communication."""
+        return eps
+
+    def train_step(self, rows, eps=None, want_loss=True):
+        return self._step(rows, self._eps(len(rows), eps), MODE_TRAIN, want_loss)
+
+    def eval_step(self, rows, eps=None, want_loss=True):
+        return self._step(rows, self._eps(len(rows), eps), MODE_EVAL, want_loss)
+
+    def grad_step(self, rows, eps=None):
+        return self._step(rows, self._eps(len(rows), eps), MODE_GRAD, True)
+
+    def get_grads_shard(self):
+        return self.eng.get_grads()
+
+    def encode(self, rows, eps=None):
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        outs = []
+        for i0 in range(0, len(rows), 32):
+            r = rows[i0:i0 + 32]
+            e = None if eps is None else eps[i0:i0 + 32]
+            self.eng.stage_a(r, self._eps(len(r), e), MODE_ENCODE)
+            self._allreduce(0)
+            outs.append(self.eng.stage_encode(len(r)))
+        return tuple(np.concatenate([o[k] for o in outs]) for k in range(3))
+
+    def train_epoch(self, perm, val_rows, eps_fn=None):
+        """One epoch of fit (K8/K9): batches of batch_size, short last batch kept; plain batch means."""
+        B = self.batch_size
+        perm = np.ascontiguousarray(perm, dtype=np.int32)
+        val_rows = np.ascontiguousarray(val_rows, dtype=np.int32)
+        tl, vl = [], []
+        for i0 in range(0, len(perm), B):
+            r = perm[i0:i0 + B]
+            tl.append(self.train_step(r, None if eps_fn is None else eps_fn(len(r)))[0])
+        for i0 in range(0, len(val_rows), B):
+            r = val_rows[i0:i0 + B]
+            vl.append(self.eval_step(r, None if eps_fn is None else eps_fn(len(r)))[0])
+        return float(np.mean(tl)), (float(np.mean(vl)) if vl else float("nan"))
+
+    def synchronize(self):
+        self.eng.synchronize()
+
+    def close(self):
+        self.eng.close()
