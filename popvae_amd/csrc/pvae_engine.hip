@@ -194,6 +194,7 @@ size_t lds_dense_fwd(int K) { return (size_t)(32 * (K + 1) + 4096) * 4; }
 size_t lds_dense_bwd(int N) { return (size_t)(2 * 32 * (N + 1) + 4096) * 4; }
 size_t lds_dec(int NWB) { return (size_t)(32 * (NWB * 32 + 1) + 4 * 3 * 32 * 33) * 4; }
 size_t lds_enc_bwd(int Wp) { return (size_t)32 * Wp * 4; }
+size_t lds_enc_fwd(int NWB) { return (size_t)4 * NWB * 1024 * 4; }
 
 template <typename Kern>
 hipError_t allow_lds(Kern k, size_t bytes) {
@@ -206,6 +207,7 @@ int setup_kernel_attrs(pvae_engine* e) {
     HIPCHK(allow_lds(pvk_dense_bwd<PV_MODE_TRAIN>, lds_dense_bwd(maxK)));
     HIPCHK(allow_lds(pvk_dense_bwd<PV_MODE_GRAD>, lds_dense_bwd(maxK)));
 #define PV_ATTR(N)                                                                    \
+    HIPCHK(allow_lds(pvk_enc_fwd<N>, lds_enc_fwd(N)));                                \
     HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_TRAIN>, lds_dec(N)));                      \
     HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_GRAD>, lds_dec(N)));                       \
     HIPCHK(allow_lds(pvk_dec<N, 0, PV_MODE_TRAIN>, lds_dec(N)));                      \
@@ -271,11 +273,11 @@ int stage_a(pvae_engine* e, int row_offset, bool need_xt) {
     }
     {
         Timer t(e, C_ENC_FWD);
-        PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_enc_fwd<N_>, dim3(e->enc_wgs), dim3(256), 0, e->stream, e->W1.w, e->geno,
+        PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_enc_fwd<N_>, dim3(e->enc_wgs), dim3(256), lds_enc_fwd(N_), e->stream, e->W1.w, e->geno,
                                               e->row_bytes, e->d_rows, e->st, row_offset, e->nblk, e->ngrp, e->encpart));
         if ((rc = launch_check(e, "enc_fwd"))) return rc;
-        PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_enc_reduce<N_>, dim3((N_ * 1024 + 255) / 256, e->ngrp), dim3(256), 0,
-                                              e->stream, e->encpart, e->enc_wgs * 4, e->ngrp, e->Wp, e->P));
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(32 * e->Wp / 64), dim3(256), 0, e->stream, e->encpart, e->enc_wgs, 32 * e->Wp,
+                           0.5f, e->P, (const float*)nullptr, (float*)nullptr);
         if ((rc = launch_check(e, "enc_reduce"))) return rc;
     }
     return 0;
@@ -336,9 +338,8 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
         if ((rc = launch_check(e, "dec"))) return rc;
         const int n_dg = mode == 1 ? 0 : 32 * e->Wp;
         // eval: only the recon sums are produced (they live behind the dg block of the exchange buffer)
-        hipLaunchKernelGGL(pvk_dec_reduce, dim3((32 * e->Wp + 32 + 255) / 256), dim3(256), 0, e->stream, e->dgpart,
-                           e->losspart, e->dec_wgs, n_dg, e->xch1,
-                           e->xch1 + 32 * e->Wp);
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(n_dg ? n_dg / 64 : 1), dim3(256), 0, e->stream, e->dgpart, e->dec_wgs, n_dg, 1.0f,
+                           e->xch1, e->losspart, e->xch1 + 32 * e->Wp);
         if ((rc = launch_check(e, "dec_reduce"))) return rc;
     }
     return 0;
@@ -663,7 +664,7 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     e->enc_wgs = clampi((tasks + 15) / 16, 1, 512);
     e->dec_wgs = clampi((e->nblk + 7) / 8, 1, 512);
     e->encb_wgs = clampi((tasks + 7) / 8, 1, 1024);
-    CK(allocf(e, &e->encpart, (int64_t)e->enc_wgs * 4 * e->NWB * 1024));
+    CK(allocf(e, &e->encpart, (int64_t)e->enc_wgs * e->NWB * 1024));
     CK(allocf(e, &e->dgpart, (int64_t)e->dec_wgs * 32 * e->Wp));
     CK(allocf(e, &e->losspart, (int64_t)e->dec_wgs));
 

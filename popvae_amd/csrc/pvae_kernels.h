@@ -52,7 +52,8 @@ __device__ __forceinline__ float pv_elu_grad_from_out(float y) { return y > 0.f 
 __device__ __forceinline__ void pv_adam(float& w, float& m, float& v, float g, float alpha, const PvAdam& A) {
     m += (g - m) * (1.f - A.b1);
     v += (g * g - v) * (1.f - A.b2);
-    w -= (m * alpha) / (sqrtf(v) + A.eps);
+    // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the ~20-instruction IEEE expansions
+    w -= (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + A.eps);
 }
 
 // code(ROW(r,h)) of a 64-bit word holding 32 2-bit codes, after pre-shifting by 8*h bits
@@ -164,26 +165,58 @@ __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1,
                 acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wv[w][r >> 2][r & 3], acc[w], 0, 0, 0);
         }
     }
-    // part layout: [gw][w][r][lane]  (row b = ROW(r,h), unit = (grp*NWB + w)*32 + c)
-    float* p = part + (int64_t)gw * (NWB * 1024);
+    // workgroup-level fixed-order reduce of the 4 waves' fragments, then one row-major partial per
+    // workgroup: part[wg][b][u]  (b = ROW(r,h), u = w*32 + c)
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][NWB*16][64]
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int w = 0; w < NWB; ++w)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) p[(w * 16 + r) * 64 + lane] = acc[w][r];
+        for (int r = 0; r < 16; ++r) red[((wave * NWB + w) * 16 + r) * 64 + lane] = acc[w][r];
+    __syncthreads();
+    float* p = part + (int64_t)blockIdx.x * (NWB * 1024);
+    for (int e = threadIdx.x; e < NWB * 1024; e += 256) {
+        const float sum = ((red[e] + red[NWB * 1024 + e]) + red[2 * NWB * 1024 + e]) + red[3 * NWB * 1024 + e];
+        const int w = e >> 10, r = (e >> 6) & 15, ln = e & 63;
+        p[PV_ROW(r, ln >> 5) * (NWB * 32) + w * 32 + (ln & 31)] = sum;
+    }
 }
 
-// P[b][u] = 0.5 * sum over waves (fixed order) ; one thread per (w, r, lane) element of a group.
-template <int NWB>
-__global__ __launch_bounds__(256) void pvk_enc_reduce(const float* __restrict__ part, int nwaves, int ngrp, int ldp,
-                                                      float* __restrict__ P) {
-    const int e = blockIdx.x * 256 + threadIdx.x;  // element inside one group fragment
-    const int grp = blockIdx.y;
-    if (e >= NWB * 1024) return;
-    float s = 0.f;
-    for (int gw = grp; gw < nwaves; gw += ngrp) s += part[(int64_t)gw * (NWB * 1024) + e];
-    const int w = e >> 10, r = (e >> 6) & 15, lane = e & 63;
-    const int b = PV_ROW(r, lane >> 5), u = (grp * NWB + w) * 32 + (lane & 31);
-    P[b * ldp + u] = 0.5f * s;
+// ---------------------------------------------------------------------------------------------
+// Fixed-order reduction of per-workgroup partials: out[e] = scale * sum_p part[p*n + e], e < n (n % 64 == 0),
+// and optionally sout[0] = sum_p spart[p].  Block = 16 float4 columns x 16 slices; slice s adds partials
+// s, s+16, ... in order, then the 16 slice sums are added in order: bitwise reproducible.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pvk_reduce_parts(const float* __restrict__ part, int nparts, int n, float scale,
+                                                        float* __restrict__ out, const float* __restrict__ spart,
+                                                        float* __restrict__ sout) {
+    __shared__ f32x4 sm[16][16];
+    __shared__ float ss[256];
+    const int tid = threadIdx.x, col = tid & 15, slice = tid >> 4;
+    if ((int)blockIdx.x * 64 < n) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(part) + blockIdx.x * 16 + col;
+        const int n4 = n >> 2;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int p = slice; p < nparts; p += 16) acc += src[(int64_t)p * n4];
+        sm[slice][col] = acc;
+    }
+    if (blockIdx.x == 0 && spart) {
+        float a = 0.f;
+        for (int p = tid; p < nparts; p += 256) a += spart[p];
+        ss[tid] = a;
+    }
+    __syncthreads();
+    if ((int)blockIdx.x * 64 < n && tid < 16) {
+        f32x4 acc = sm[0][tid];
+#pragma unroll
+        for (int s2 = 1; s2 < 16; ++s2) acc += sm[s2][tid];
+        reinterpret_cast<f32x4*>(out)[blockIdx.x * 16 + tid] = acc * scale;
+    }
+    if (blockIdx.x == 0 && spart && tid == 0) {
+        float a = 0.f;
+        for (int i = 0; i < 256; ++i) a += ss[i];
+        sout[0] = a;
+    }
 }
 
 // h = act(P + bias)  (first encoder layer epilogue; after the SNP-shard all-reduce when world > 1)
@@ -465,8 +498,8 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(float* __restrict__ V, float* 
             const float x = 0.5f * pv_code(lo, hi, r);
             const float z = a[r] + bias;
             const float e = __expf(-fabsf(z));                 // exp(-|z|)
-            const float bce = fmaxf(z, 0.f) - z * x + log1pf(e);
-            const float inv = 1.f / (1.f + e);
+            const float bce = fmaxf(z, 0.f) - z * x + __logf(1.f + e);
+            const float inv = __builtin_amdgcn_rcpf(1.f + e);
             const float p = z >= 0.f ? inv : e * inv;            // sigmoid(z)
             const bool ok = lvalid && (b < nrows);
             lossacc += ok ? bce : 0.f;
@@ -572,24 +605,6 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(float* __restrict__ V, float* 
             const int w = e >> 10, r = (e >> 6) & 15, ln = e & 63;
             dgpart[(int64_t)blockIdx.x * (32 * WP) + PV_ROW(r, ln >> 5) * WP + w * 32 + (ln & 31)] = s;
         }
-    }
-}
-
-// dgD[b][u] = sum_wg dgpart (fixed order) ; recon[0] = sum_wg losspart (recon[1..31] = 0).
-// grid covers 32*Wp + 32 elements.
-__global__ void pvk_dec_reduce(const float* __restrict__ dgpart, const float* __restrict__ losspart, int nwg, int n_dg,
-                               float* __restrict__ dg, float* __restrict__ recon) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_dg) {
-        float s = 0.f;
-        for (int w = 0; w < nwg; ++w) s += dgpart[(int64_t)w * n_dg + i];
-        dg[i] = s;
-    } else if (i < n_dg + 32) {
-        const int b = i - n_dg;
-        float s = 0.f;
-        if (b == 0)
-            for (int w = 0; w < nwg; ++w) s += losspart[w];
-        recon[b] = s;
     }
 }
 

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Kernel-level timing at a BASELINE shape without torch: python tools/kbench.py [C4|C2] [steps]
+Prints per-kernel-category HIP-event averages and the implied GB/s."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from popvae_amd import engine as E  # noqa: E402
+
+SH = {"C4": (2504, 1_000_000, 128, 6), "C2": (1000, 100_000, 128, 6), "C1": (95, 3887, 128, 6)}
+name = sys.argv[1] if len(sys.argv) > 1 else "C4"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+N, L, W, D = SH[name]
+g = np.random.default_rng(0)
+lut = np.arange(256, dtype=np.uint8)
+for sh in (0, 2, 4, 6):
+    bad = ((lut >> sh) & 3) == 3
+    lut[bad] &= ~np.uint8(2 << sh) & 0xFF
+rb = (L + 31) // 32 * 8
+packed = lut[g.integers(0, 256, size=(N, rb), dtype=np.uint8)]
+if L % 32:
+    packed[:, L // 4 + 1:] = 0
+    packed[:, L // 4] &= (1 << (2 * (L % 4))) - 1
+e = E.Engine(n_snps=L, width=W, depth=D, latent_dim=2, batch_size=32, seed=1)
+e.load_genotypes(packed)
+e.init_weights(1)
+rows = np.concatenate([g.permutation(N) for _ in range(steps * 32 // N + 2)])[:steps * 32].astype(np.int32)
+e.train_epoch(rows[:5 * 32], np.zeros(0, np.int32))
+e.set_timing(True)
+t0 = time.perf_counter()
+loss, _ = e.train_epoch(rows, np.zeros(0, np.int32))
+dt = time.perf_counter() - t0
+Wp = (W + 31) // 32 * 32
+algo = {"dec": 24 * L * Wp + 32 * L, "enc_fwd": 4 * L * Wp + 8 * L, "enc_bwd": 24 * L * Wp + 8 * L}
+print(f"{name}: {dt / steps * 1e3:.3f} ms/step  {steps * 32 / dt:.0f} samples/s  loss {loss:.3f}")
+tot = 0
+for k in ("gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd"):
+    ms, n = e.get_timing(k)
+    if n:
+        a = ms / n
+        tot += a
+        extra = f"  {algo[k] / a / 1e6:8.0f} GB/s" if k in algo else ""
+        print(f"  {k:11s} {a * 1e3:9.1f} us{extra}")
+print(f"  sum         {tot * 1e3:9.1f} us")
+vr = rows[:8 * 32].reshape(8, 32)
+e.set_timing(False)
+e.synchronize()
+t0 = time.perf_counter()
+for r in vr:
+    e.eval_step(r, None, want_loss=False)
+e.synchronize()
+print(f"  eval step   {(time.perf_counter() - t0) / 8 * 1e3:.3f} ms")
