@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -20,6 +21,7 @@
 
 #include "../../include/pvae.h"
 #include "pvae_kernels.h"
+#include "pvae_narrow.h"
 
 #define PV_VERSION "popvae_amd 0.1.0 (gfx950)"
 
@@ -75,6 +77,12 @@ struct pvae_engine {
     // scratch
     float *encpart = nullptr, *dgpart = nullptr, *losspart = nullptr;
     int enc_wgs = 0, dec_wgs = 0, encb_wgs = 0;
+    // fused narrow stack (width <= 128): op tables in device memory
+    bool fused_narrow = false;
+    PvFwdOp* d_fwd_ops = nullptr;
+    PvBwdOp *d_bwd_ops = nullptr, *d_bwd_ops_grad = nullptr;
+    std::vector<float*> dpre_bufs;  // per narrow dense layer, [32][nout]
+    int n_fwd_ops = 0, n_enc_ops = 0, n_bwd_ops = 0;
     // step state
     PvStep* st = nullptr;
     int* d_rows = nullptr;
@@ -206,6 +214,9 @@ int setup_kernel_attrs(pvae_engine* e) {
     HIPCHK(allow_lds(pvk_dense_fwd, lds_dense_fwd(maxK)));
     HIPCHK(allow_lds(pvk_dense_bwd<PV_MODE_TRAIN>, lds_dense_bwd(maxK)));
     HIPCHK(allow_lds(pvk_dense_bwd<PV_MODE_GRAD>, lds_dense_bwd(maxK)));
+    HIPCHK(allow_lds(pvk_narrow_fwd, pvn_lds_fwd()));
+    HIPCHK(allow_lds(pvk_narrow_bwd<PV_MODE_TRAIN>, pvn_lds_bwd()));
+    HIPCHK(allow_lds(pvk_narrow_bwd<PV_MODE_GRAD>, pvn_lds_bwd()));
 #define PV_ATTR(N)                                                                    \
     HIPCHK(allow_lds(pvk_enc_fwd<N>, lds_enc_fwd(N)));                                \
     HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_TRAIN>, lds_dec(N)));                      \
@@ -283,9 +294,72 @@ int stage_a(pvae_engine* e, int row_offset, bool need_xt) {
     return 0;
 }
 
+// op tables of the fused narrow kernels (pvae_narrow.h); grad = true builds the gradient-dump variant
+int build_bwd_ops(pvae_engine* e, bool grad, PvBwdOp** out) {
+    std::vector<PvBwdOp> ops;
+    size_t nd = 0;
+    auto dense = [&](Dense& d, const float* in, const float* Y) {
+        PvBwdOp o{};
+        if (nd == e->dpre_bufs.size()) {
+            float* p = nullptr;
+            if (hipMalloc(&p, (size_t)32 * d.nout * sizeof(float)) != hipSuccess) p = nullptr;
+            e->dpre_bufs.push_back(p);
+        }
+        o.dpre = e->dpre_bufs[nd++];
+        o.W = d.W.w; o.mW = grad ? d.W.g : d.W.m; o.vW = grad ? nullptr : d.W.v;
+        o.B = d.B.w; o.mB = grad ? d.B.g : d.B.m; o.vB = grad ? nullptr : d.B.v;
+        o.in = in; o.Y = Y; o.kin = d.kin; o.nout = d.nout; o.act = d.act; o.kind = PVN_DENSE;
+        ops.push_back(o);
+    };
+    const int D = e->D;
+    for (int i = D - 1; i >= 1; --i) dense(e->dec[i], e->g[i - 1], e->g[i]);
+    dense(e->dec[0], e->z, e->g[0]);
+    PvBwdOp r{};
+    r.kind = PVN_REPARAM; r.nout = e->Kh; r.kin = e->Kz;
+    ops.push_back(r);
+    dense(e->heads, e->h[D - 1], e->headout);
+    for (int i = D - 2; i >= 0; --i) dense(e->enc[i], e->h[i], e->h[i + 1]);
+    PvBwdOp f{};
+    f.kind = PVN_FIRST_BIAS; f.dpre = e->dpre1; f.B = e->b1.w; f.mB = grad ? e->b1.g : e->b1.m; f.vB = grad ? nullptr : e->b1.v;
+    f.Y = e->h[0]; f.nout = e->Wp; f.kin = 0; f.act = PV_ACT_ELU;
+    ops.push_back(f);
+    e->n_bwd_ops = (int)ops.size();
+    for (auto p : e->dpre_bufs)
+        if (!p) return set_err(e, -10, "hipMalloc failed for a dpre buffer");
+    if (!*out) HIPCHK(hipMalloc(out, ops.size() * sizeof(PvBwdOp)));
+    HIPCHK(hipMemcpy(*out, ops.data(), ops.size() * sizeof(PvBwdOp), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int build_fwd_ops(pvae_engine* e) {
+    std::vector<PvFwdOp> ops;
+    auto dense = [&](const Dense& d, float* out) {
+        ops.push_back(PvFwdOp{d.W.w, d.B.w, out, d.kin, d.nout, d.act, PVN_DENSE});
+    };
+    const int D = e->D;
+    ops.push_back(PvFwdOp{nullptr, e->b1.w, e->h[0], 0, e->Wp, PV_ACT_ELU, PVN_BIAS_ACT});
+    for (int i = 0; i < D - 1; ++i) dense(e->enc[i], e->h[i + 1]);
+    dense(e->heads, e->headout);
+    ops.push_back(PvFwdOp{nullptr, nullptr, nullptr, e->Kh, e->Kz, PV_ACT_LINEAR, PVN_REPARAM});
+    e->n_enc_ops = (int)ops.size();
+    dense(e->dec[0], e->g[0]);
+    for (int i = 1; i < D; ++i) dense(e->dec[i], e->g[i]);
+    e->n_fwd_ops = (int)ops.size();
+    HIPCHK(hipMalloc(&e->d_fwd_ops, ops.size() * sizeof(PvFwdOp)));
+    HIPCHK(hipMemcpy(e->d_fwd_ops, ops.data(), ops.size() * sizeof(PvFwdOp), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int narrow_fused_fwd(pvae_engine* e, bool encoder_only) {
+    hipLaunchKernelGGL(pvk_narrow_fwd, dim3(1), dim3(PVN_THREADS), pvn_lds_fwd(), e->stream, e->d_fwd_ops,
+                       encoder_only ? e->n_enc_ops : e->n_fwd_ops, e->P, e->eps, e->K, e->Kz, e->z, e->kl);
+    return launch_check(e, "narrow_fwd");
+}
+
 // narrow encoder: h1 = elu(P + b1), hidden layers, heads, reparameterisation + KL
 int narrow_encoder(pvae_engine* e) {
     int rc;
+    if (e->fused_narrow) return narrow_fused_fwd(e, true);
     hipLaunchKernelGGL(pvk_bias_act, dim3((32 * e->Wp + 255) / 256), dim3(256), 0, e->stream, e->P, e->b1.w, e->Wp,
                        (int)PV_ACT_ELU, e->h[0]);
     if ((rc = launch_check(e, "bias_act"))) return rc;
@@ -309,8 +383,12 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
     int rc;
     {
         Timer t(e, C_NARROW_FWD);
-        if ((rc = narrow_encoder(e))) return rc;
-        if ((rc = narrow_decoder(e))) return rc;
+        if (e->fused_narrow) {
+            if ((rc = narrow_fused_fwd(e, false))) return rc;
+        } else {
+            if ((rc = narrow_encoder(e))) return rc;
+            if ((rc = narrow_decoder(e))) return rc;
+        }
     }
     {
         Timer t(e, C_DEC);
@@ -345,9 +423,53 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
     return 0;
 }
 
+int enc_bwd_launch(pvae_engine* e, int km) {
+    int rc;
+    Timer t(e, C_ENC_BWD);
+    if (km == PV_MODE_GRAD) {
+        if (!e->W1.g && (rc = allocf(e, &e->W1.g, e->W1.n))) return rc;
+        PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_GRAD>), dim3(e->encb_wgs), dim3(256),
+                                              lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.g, (float*)nullptr, e->dpre1,
+                                              e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam));
+    } else {
+        PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN>), dim3(e->encb_wgs), dim3(256),
+                                              lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->dpre1, e->Wp,
+                                              e->Xt, e->nblk, e->ngrp, e->st, e->adam));
+    }
+    return launch_check(e, "enc_bwd");
+}
+
 // stage C: loss, narrow backward (+Adam), wide encoder backward (+Adam)
 int stage_c(pvae_engine* e, int mode, float* d_out3) {
     int rc;
+    if (e->fused_narrow) {
+        {
+        Timer t(e, C_NARROW_BWD);
+        if (mode == 2) {
+            if (!e->d_bwd_ops_grad) {
+                int rc2 = 0;
+                for_each_buf(e, [&](Buf3& b) { if (!rc2 && !b.g) rc2 = allocf(e, &b.g, b.n); });
+                if (rc2) return rc2;
+                if ((rc = build_bwd_ops(e, true, &e->d_bwd_ops_grad))) return rc;
+            }
+            hipLaunchKernelGGL(pvk_narrow_bwd<PV_MODE_GRAD>, dim3(1), dim3(PVN_THREADS), pvn_lds_bwd(), e->stream,
+                               e->d_bwd_ops_grad, e->n_bwd_ops, e->xch1, e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st,
+                               e->adam, d_out3, 1);
+            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_GRAD>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, e->d_bwd_ops_grad,
+                               e->st, e->adam);
+        } else {
+            hipLaunchKernelGGL(pvk_narrow_bwd<PV_MODE_TRAIN>, dim3(1), dim3(PVN_THREADS), pvn_lds_bwd(), e->stream,
+                               e->d_bwd_ops, e->n_bwd_ops, e->xch1, e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st,
+                               e->adam, d_out3, mode == 0 ? 1 : 0);
+            if (mode == 0)
+                hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, e->d_bwd_ops,
+                                   e->st, e->adam);
+        }
+        if ((rc = launch_check(e, "narrow_bwd"))) return rc;
+        }
+        if (mode == 1) return 0;
+        return enc_bwd_launch(e, mode == 2 ? PV_MODE_GRAD : PV_MODE_TRAIN);
+    }
     hipLaunchKernelGGL(pvk_loss_final, dim3(1), dim3(64), 0, e->stream, e->xch1 + 32 * e->Wp, e->kl, e->st, d_out3);
     if ((rc = launch_check(e, "loss_final"))) return rc;
     if (mode == 1) return 0;
@@ -387,21 +509,7 @@ int stage_c(pvae_engine* e, int mode, float* d_out3) {
         }
         if ((rc = launch_check(e, "bias_bwd"))) return rc;
     }
-    {
-        Timer t(e, C_ENC_BWD);
-        if (km == PV_MODE_GRAD) {
-            if (!e->W1.g && (rc = allocf(e, &e->W1.g, e->W1.n))) return rc;
-            PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_GRAD>), dim3(e->encb_wgs), dim3(256),
-                                                  lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.g, (float*)nullptr, e->dpre1,
-                                                  e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam));
-        } else {
-            PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN>), dim3(e->encb_wgs), dim3(256),
-                                                  lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->dpre1, e->Wp,
-                                                  e->Xt, e->nblk, e->ngrp, e->st, e->adam));
-        }
-        if ((rc = launch_check(e, "enc_bwd"))) return rc;
-    }
-    return 0;
+    return enc_bwd_launch(e, km);
 }
 
 int ensure_rows(pvae_engine* e, int64_t n) {
@@ -556,6 +664,11 @@ inline float hash_uniform(uint64_t seed, uint64_t tensor, uint64_t idx) {
 extern "C" {
 
 const char* pvae_version(void) { return PV_VERSION; }
+#ifdef PVN_TRACE
+int pvae_debug_trace(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pvn_trace_buf), n * sizeof(unsigned long long));
+}
+#endif
 
 int pvae_device_count(void) {
     int n = 0;
@@ -678,6 +791,11 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     CK(ensure_rows(e, 4096));
     CK(ensure_loss(e, 1024));
     CK(setup_kernel_attrs(e));
+    e->fused_narrow = e->Wp <= 128 && 2 * e->D + 2 <= PVN_MAXOPS && !getenv("PVAE_NO_FUSED_NARROW");
+    if (e->fused_narrow) {
+        CK(build_fwd_ops(e));
+        CK(build_bwd_ops(e, false, &e->d_bwd_ops));
+    }
 #undef CK
 #undef HK
     *out = e;
@@ -694,6 +812,8 @@ int pvae_destroy(pvae_engine* e) {
     float* fl[] = {e->P, e->headout, e->dheads, e->z, e->dz, e->kl, e->eps, e->xch1, e->dA, e->dB, e->dpre1,
                    e->encpart, e->dgpart, e->losspart, e->d_loss};
     for (auto p : fl) hipFree(p);
+    hipFree(e->d_fwd_ops); hipFree(e->d_bwd_ops); hipFree(e->d_bwd_ops_grad);
+    for (auto p : e->dpre_bufs) hipFree(p);
     hipFree(e->Xt); hipFree(e->geno); hipFree(e->st); hipFree(e->d_rows); hipFree(e->d_ntotal); hipFree(e->d_counter);
     for (auto& ev : e->evs) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     for (auto& sl : e->slots) { if (sl.host) hipHostFree(sl.host); if (sl.ev) hipEventDestroy(sl.ev); }

@@ -45,7 +45,9 @@ struct PvAdam {
     float b1, b2, eps;
 };
 
-__device__ __forceinline__ float pv_elu(float x) { return x > 0.f ? x : expm1f(x); }
+// ELU(alpha = 1).  exp via v_exp_f32 (abs. error ~1e-7 on a value in (-1, 0]) instead of the ~60-instruction expm1f:
+// the narrow stack runs on one CU, where VALU instruction count is wall time.
+__device__ __forceinline__ float pv_elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 // derivative of ELU expressed through its output y (alpha = 1): y > 0 ? 1 : y + 1
 __device__ __forceinline__ float pv_elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
 
