@@ -10,6 +10,7 @@
 //   scratch  split-K partials of the two wide kernels, activations, Xt (transposed batch codes)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -29,7 +30,11 @@ namespace {
 
 struct Buf3 {  // weight + Adam slots (+ lazily allocated gradient dump / best snapshot)
     float *w = nullptr, *m = nullptr, *v = nullptr, *g = nullptr, *best = nullptr;
+    // wide tensors only: the "other" copy.  A train step streams w/m/v -> w2/m2/v2 and swaps: in-place
+    // read-modify-write tops out ~15% below what separate read and write streams reach on HBM3E.
+    float *w2 = nullptr, *m2 = nullptr, *v2 = nullptr;
     int64_t n = 0;
+    void swap() { std::swap(w, w2); std::swap(m, m2); std::swap(v, v2); }
 };
 
 struct Dense {  // narrow layer, padded row-major [kin][nout]
@@ -138,8 +143,15 @@ int alloc3(pvae_engine* e, Buf3& b, int64_t n) {
     HIPCHK(hipMemset(b.v, 0, n * sizeof(float)));
     return 0;
 }
+int alloc_pingpong(pvae_engine* e, Buf3& b) {
+    HIPCHK(hipMalloc(&b.w2, b.n * sizeof(float)));
+    HIPCHK(hipMalloc(&b.m2, b.n * sizeof(float)));
+    HIPCHK(hipMalloc(&b.v2, b.n * sizeof(float)));
+    return 0;
+}
 void free3(Buf3& b) {
     hipFree(b.w); hipFree(b.m); hipFree(b.v); hipFree(b.g); hipFree(b.best);
+    hipFree(b.w2); hipFree(b.m2); hipFree(b.v2);
     b = Buf3();
 }
 int allocf(pvae_engine* e, float** p, int64_t n) {
@@ -399,19 +411,21 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
         }
         if (mode == 0) {
             PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 1, PV_MODE_TRAIN>), dim3(e->dec_wgs), dim3(256), lds_dec(N_),
-                                                  e->stream, e->Vout.w, e->Vout.m, e->Vout.v, e->cout.w, e->cout.m,
-                                                  e->cout.v, gD, e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart,
-                                                  e->losspart));
+                                                  e->stream, e->Vout.w, e->Vout.m, e->Vout.v, e->Vout.w2, e->Vout.m2,
+                                                  e->Vout.v2, e->cout.w, e->cout.m, e->cout.v, gD, e->Xt, e->nblk,
+                                                  (int)e->L, e->st, e->adam, e->dgpart, e->losspart));
+            e->Vout.swap();
         } else if (mode == 2) {
             PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 1, PV_MODE_GRAD>), dim3(e->dec_wgs), dim3(256), lds_dec(N_),
-                                                  e->stream, e->Vout.w, e->Vout.g, (float*)nullptr, e->cout.w, e->cout.g,
-                                                  (float*)nullptr, gD, e->Xt, e->nblk, (int)e->L, e->st, e->adam,
-                                                  e->dgpart, e->losspart));
+                                                  e->stream, e->Vout.w, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                                                  e->Vout.g, (float*)nullptr, e->cout.w, e->cout.g, (float*)nullptr, gD,
+                                                  e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart, e->losspart));
         } else {
             PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 0, PV_MODE_TRAIN>), dim3(e->dec_wgs), dim3(256), lds_dec(N_),
-                                                  e->stream, e->Vout.w, (float*)nullptr, (float*)nullptr, e->cout.w,
-                                                  (float*)nullptr, (float*)nullptr, gD, e->Xt, e->nblk, (int)e->L, e->st,
-                                                  e->adam, e->dgpart, e->losspart));
+                                                  e->stream, e->Vout.w, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                                                  (float*)nullptr, (float*)nullptr, e->cout.w, (float*)nullptr,
+                                                  (float*)nullptr, gD, e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart,
+                                                  e->losspart));
         }
         if ((rc = launch_check(e, "dec"))) return rc;
         const int n_dg = mode == 1 ? 0 : 32 * e->Wp;
@@ -429,12 +443,14 @@ int enc_bwd_launch(pvae_engine* e, int km) {
     if (km == PV_MODE_GRAD) {
         if (!e->W1.g && (rc = allocf(e, &e->W1.g, e->W1.n))) return rc;
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_GRAD>), dim3(e->encb_wgs), dim3(256),
-                                              lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.g, (float*)nullptr, e->dpre1,
-                                              e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam));
+                                              lds_enc_bwd(e->Wp), e->stream, e->W1.w, (float*)nullptr, (float*)nullptr,
+                                              (float*)nullptr, e->W1.g, (float*)nullptr, e->dpre1, e->Wp, e->Xt, e->nblk,
+                                              e->ngrp, e->st, e->adam));
     } else {
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN>), dim3(e->encb_wgs), dim3(256),
-                                              lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->dpre1, e->Wp,
-                                              e->Xt, e->nblk, e->ngrp, e->st, e->adam));
+                                              lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
+                                              e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam));
+        e->W1.swap();
     }
     return launch_check(e, "enc_bwd");
 }
@@ -722,6 +738,8 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     const int64_t wide_n = (int64_t)e->nblk * e->ngrp * e->NWB * 1024;
     CK(alloc3(e, e->W1, wide_n));
     CK(alloc3(e, e->Vout, wide_n));
+    CK(alloc_pingpong(e, e->W1));
+    CK(alloc_pingpong(e, e->Vout));
     CK(alloc3(e, e->cout, e->Lp));
     CK(alloc3(e, e->b1, e->Wp));
     e->enc.resize(e->D - 1);
@@ -774,9 +792,29 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
 
     const int64_t tasks = (int64_t)e->nblk * e->ngrp;
     auto clampi = [](int64_t v, int64_t lo, int64_t hi) { return (int)std::min(hi, std::max(lo, v)); };
-    e->enc_wgs = clampi((tasks + 15) / 16, 1, 512);
-    e->dec_wgs = clampi((e->nblk + 7) / 8, 1, 512);
-    e->encb_wgs = clampi((tasks + 7) / 8, 1, 1024);
+    // the wide kernels are persistent-style: the grid is exactly what is co-resident (CUs x blocks per CU), so that
+    // every wave streams the same number of subtiles and there is no second, partly filled round
+    {
+        hipDeviceProp_t prop;
+        HK(hipGetDeviceProperties(&prop, e->dev));
+        const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        int o_enc = 1, o_dec = 1, o_encb = 1;
+        PV_DISPATCH_NWB(e, {
+            HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_enc, pvk_enc_fwd<N_>, 256, lds_enc_fwd(N_)));
+            HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, pvk_dec<N_, 1, PV_MODE_TRAIN>, 256, lds_dec(N_)));
+            HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_encb, pvk_enc_bwd<N_, PV_MODE_TRAIN>, 256, lds_enc_bwd(e->Wp)));
+        });
+        auto envi = [](const char* k, int dflt) { const char* v = getenv(k); return v && *v ? atoi(v) : dflt; };
+        o_enc = envi("PVAE_ENC_OCC", std::min(std::max(o_enc, 1), 2));
+        o_dec = envi("PVAE_DEC_OCC", std::max(o_dec, 1));
+        o_encb = envi("PVAE_ENCB_OCC", std::max(o_encb, 1));
+        e->enc_wgs = clampi((tasks + 3) / 4, 1, (int64_t)cus * o_enc);
+        e->dec_wgs = clampi((e->nblk + 3) / 4, 1, (int64_t)cus * o_dec);
+        e->encb_wgs = clampi((tasks + 3) / 4, 1, (int64_t)cus * o_encb);
+        if (getenv("PVAE_VERBOSE"))
+            fprintf(stderr, "[pvae] CUs %d; blocks/CU enc_fwd %d dec %d enc_bwd %d; grids %d %d %d\n", cus, o_enc, o_dec, o_encb,
+                    e->enc_wgs, e->dec_wgs, e->encb_wgs);
+    }
     CK(allocf(e, &e->encpart, (int64_t)e->enc_wgs * e->NWB * 1024));
     CK(allocf(e, &e->dgpart, (int64_t)e->dec_wgs * 32 * e->Wp));
     CK(allocf(e, &e->losspart, (int64_t)e->dec_wgs));

@@ -432,7 +432,9 @@ __global__ void pvk_reparam_bwd(const float* __restrict__ heads, int ldh, int K,
 // TRAIN: 0 = evaluation (loss only), 1 = training.
 // ---------------------------------------------------------------------------------------------
 template <int NWB, int TRAIN, int MODE>
-__global__ __launch_bounds__(256, 2) void pvk_dec(float* __restrict__ V, float* __restrict__ mV, float* __restrict__ vV,
+__global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, const float* __restrict__ mV,
+                                                  const float* __restrict__ vV, float* __restrict__ V2,
+                                                  float* __restrict__ mV2, float* __restrict__ vV2,
                                                   float* __restrict__ cb, float* __restrict__ mC, float* __restrict__ vC,
                                                   const float* __restrict__ g, const uint64_t* __restrict__ Xt,
                                                   int nblk, int L, const PvStep* st, PvAdam adam,
@@ -469,12 +471,12 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(float* __restrict__ V, float* 
         // keep the (loop-invariant) g operand reads inside the loop: hoisting them costs 128 VGPRs
         asm volatile("" ::: "memory");
         const int64_t tbase = (int64_t)blk * (NWB * 256);  // in f32x4 units
-        f32x4* tV = reinterpret_cast<f32x4*>(V) + tbase;
+        const f32x4* tV = reinterpret_cast<const f32x4*>(V) + tbase;
         f32x4 vv[NWB][4];
 #pragma unroll
         for (int w = 0; w < NWB; ++w)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) vv[w][q] = tV[(w * 4 + q) * 64 + lane];
+            for (int q = 0; q < 4; ++q) vv[w][q] = __builtin_nontemporal_load(tV + (w * 4 + q) * 64 + lane);
         const int l = blk * 32 + c;
         const bool lvalid = l < L;
         const float bias = cb[l];
@@ -544,8 +546,11 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(float* __restrict__ V, float* 
                 __builtin_amdgcn_sched_barrier(0);
             }
             // (4) dV[unit][l] = sum_b g[b][unit] * da[b][l] : M = unit, N = l, K = b ; then Adam
-            f32x4* tM = reinterpret_cast<f32x4*>(mV) + tbase;
-            f32x4* tVv = reinterpret_cast<f32x4*>(vV) + tbase;
+            const f32x4* tM = reinterpret_cast<const f32x4*>(mV) + tbase;
+            const f32x4* tVv = reinterpret_cast<const f32x4*>(vV) + tbase;
+            f32x4* dV2 = reinterpret_cast<f32x4*>(V2) + tbase;
+            f32x4* dM2 = reinterpret_cast<f32x4*>(mV2) + tbase;
+            f32x4* dVv2 = reinterpret_cast<f32x4*>(vV2) + tbase;
 #pragma unroll
             for (int w = 0; w < NWB; ++w) {
                 f32x16 dv;
@@ -561,9 +566,9 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(float* __restrict__ V, float* 
                     const int off = (w * 4 + q) * 64 + lane;
                     if (MODE == PV_MODE_GRAD) {
                         f32x4 gq = {dv[q * 4 + 0], dv[q * 4 + 1], dv[q * 4 + 2], dv[q * 4 + 3]};
-                        tM[off] = gq;
+                        dM2[off] = gq;
                     } else {
-                        f32x4 wq = vv[w][q], mq = tM[off], vq = tVv[off];
+                        f32x4 wq = vv[w][q], mq = __builtin_nontemporal_load(tM + off), vq = __builtin_nontemporal_load(tVv + off);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float w_ = wq[e], m_ = mq[e], v_ = vq[e];
@@ -572,9 +577,9 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(float* __restrict__ V, float* 
                             mq[e] = m_;
                             vq[e] = v_;
                         }
-                        tV[off] = wq;
-                        tM[off] = mq;
-                        tVv[off] = vq;
+                        __builtin_nontemporal_store(wq, dV2 + off);
+                        __builtin_nontemporal_store(mq, dM2 + off);
+                        __builtin_nontemporal_store(vq, dVv2 + off);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -628,7 +633,9 @@ __global__ void pvk_loss_final(const float* __restrict__ recon, const float* __r
 // One wave per subtile; dpre1 staged once per workgroup in LDS.
 // ---------------------------------------------------------------------------------------------
 template <int NWB, int MODE>
-__global__ __launch_bounds__(256) void pvk_enc_bwd(float* __restrict__ W1, float* __restrict__ mW, float* __restrict__ vW,
+__global__ __launch_bounds__(256) void pvk_enc_bwd(const float* __restrict__ W1, const float* __restrict__ mW,
+                                                   const float* __restrict__ vW, float* __restrict__ W1o,
+                                                   float* __restrict__ mWo, float* __restrict__ vWo,
                                                    const float* __restrict__ dpre, int ldp, const uint64_t* __restrict__ Xt,
                                                    int nblk, int ngrp, const PvStep* st, PvAdam adam) {
     constexpr int WG_UNITS = NWB * 32;
@@ -653,9 +660,12 @@ __global__ __launch_bounds__(256) void pvk_enc_bwd(float* __restrict__ W1, float
         float xa[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) xa[r] = pv_code(lo, hi, r);
-        f32x4* tW = reinterpret_cast<f32x4*>(W1) + t * (NWB * 256);
-        f32x4* tM = reinterpret_cast<f32x4*>(mW) + t * (NWB * 256);
-        f32x4* tV = reinterpret_cast<f32x4*>(vW) + t * (NWB * 256);
+        const f32x4* tW = reinterpret_cast<const f32x4*>(W1) + t * (NWB * 256);
+        const f32x4* tM = reinterpret_cast<const f32x4*>(mW) + t * (NWB * 256);
+        const f32x4* tV = reinterpret_cast<const f32x4*>(vW) + t * (NWB * 256);
+        f32x4* oW = reinterpret_cast<f32x4*>(W1o) + t * (NWB * 256);
+        f32x4* oM = reinterpret_cast<f32x4*>(mWo) + t * (NWB * 256);
+        f32x4* oV = reinterpret_cast<f32x4*>(vWo) + t * (NWB * 256);
 #pragma unroll
         for (int w = 0; w < NWB; ++w) {
             f32x16 dw;
@@ -671,9 +681,10 @@ __global__ __launch_bounds__(256) void pvk_enc_bwd(float* __restrict__ W1, float
                 const int off = (w * 4 + q) * 64 + lane;
                 if (MODE == PV_MODE_GRAD) {
                     f32x4 gq = {0.5f * dw[q * 4 + 0], 0.5f * dw[q * 4 + 1], 0.5f * dw[q * 4 + 2], 0.5f * dw[q * 4 + 3]};
-                    tM[off] = gq;
+                    oM[off] = gq;
                 } else {
-                    f32x4 wq = tW[off], mq = tM[off], vq = tV[off];
+                    f32x4 wq = __builtin_nontemporal_load(tW + off), mq = __builtin_nontemporal_load(tM + off),
+                          vq = __builtin_nontemporal_load(tV + off);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float w_ = wq[e], m_ = mq[e], v_ = vq[e];
@@ -682,9 +693,9 @@ __global__ __launch_bounds__(256) void pvk_enc_bwd(float* __restrict__ W1, float
                         mq[e] = m_;
                         vq[e] = v_;
                     }
-                    tW[off] = wq;
-                    tM[off] = mq;
-                    tV[off] = vq;
+                    __builtin_nontemporal_store(wq, oW + off);
+                    __builtin_nontemporal_store(mq, oM + off);
+                    __builtin_nontemporal_store(vq, oV + off);
                 }
             }
         }

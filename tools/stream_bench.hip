@@ -1,0 +1,156 @@
+// Ceiling finder for the wide-layer access pattern: in-place read-modify-write of 1 or 3 float arrays.
+// hipcc --offload-arch=gfx950 -O3 -o tools/stream_bench tools/stream_bench.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// A: grid-stride, one float4 per lane per iteration, NARR arrays updated in place
+template <int NARR, int NT>
+__global__ __launch_bounds__(256) void k_stride(f32x4* a, f32x4* b, f32x4* c, size_t n4) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    for (; i < n4; i += st) {
+        f32x4 x = NT ? __builtin_nontemporal_load(a + i) : a[i];
+        f32x4 y = {0, 0, 0, 0}, z = {0, 0, 0, 0};
+        if (NARR == 3) { y = NT ? __builtin_nontemporal_load(b + i) : b[i]; z = NT ? __builtin_nontemporal_load(c + i) : c[i]; }
+        x = x * 1.0001f + y * 0.001f;
+        if (NARR == 3) { y = y * 0.9f + z; z = z * 0.999f + x; }
+        if (NT) { __builtin_nontemporal_store(x, a + i); if (NARR == 3) { __builtin_nontemporal_store(y, b + i); __builtin_nontemporal_store(z, c + i); } }
+        else { a[i] = x; if (NARR == 3) { b[i] = y; c[i] = z; } }
+    }
+}
+
+// B: each wave owns contiguous chunks of CH KB (per array), UNR float4 loads per lane in flight per array
+template <int NARR, int UNR, int NT>
+__global__ __launch_bounds__(256) void k_chunk(f32x4* a, f32x4* b, f32x4* c, size_t nchunks /* of UNR*64 float4 */) {
+    const int lane = threadIdx.x & 63;
+    const size_t gw = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (size_t)gridDim.x * 4;
+    const size_t per = (nchunks + nw - 1) / nw;
+    size_t c0 = gw * per, c1 = c0 + per;
+    if (c1 > nchunks) c1 = nchunks;
+    for (size_t ch = c0; ch < c1; ++ch) {
+        f32x4 x[UNR], y[UNR], z[UNR];
+        f32x4* pa = a + ch * UNR * 64 + lane;
+        f32x4* pb = b + ch * UNR * 64 + lane;
+        f32x4* pc = c + ch * UNR * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            x[u] = NT ? __builtin_nontemporal_load(pa + u * 64) : pa[u * 64];
+            if (NARR == 3) { y[u] = NT ? __builtin_nontemporal_load(pb + u * 64) : pb[u * 64]; z[u] = NT ? __builtin_nontemporal_load(pc + u * 64) : pc[u * 64]; }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            x[u] = x[u] * 1.0001f;
+            if (NARR == 3) { x[u] += y[u] * 0.001f; y[u] = y[u] * 0.9f + z[u]; z[u] = z[u] * 0.999f + x[u]; }
+            if (NT) { __builtin_nontemporal_store(x[u], pa + u * 64); if (NARR == 3) { __builtin_nontemporal_store(y[u], pb + u * 64); __builtin_nontemporal_store(z[u], pc + u * 64); } }
+            else { pa[u * 64] = x[u]; if (NARR == 3) { pb[u * 64] = y[u]; pc[u * 64] = z[u]; } }
+        }
+    }
+}
+
+// B2: chunked, out-of-place, chunk assignment either contiguous per wave (RR=0) or round-robin over waves (RR=1)
+template <int UNR, int RR>
+__global__ __launch_bounds__(256) void k_chunk_oop(const f32x4* a, const f32x4* b, const f32x4* c, f32x4* a2, f32x4* b2, f32x4* c2,
+                                                   size_t nchunks) {
+    const int lane = threadIdx.x & 63;
+    const size_t gw = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (size_t)gridDim.x * 4;
+    const size_t per = (nchunks + nw - 1) / nw;
+    for (size_t it = 0; it < per; ++it) {
+        const size_t ch = RR ? it * nw + gw : gw * per + it;
+        if (ch >= nchunks) break;
+        f32x4 x[UNR], y[UNR], z[UNR];
+        const size_t o = ch * UNR * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            x[u] = __builtin_nontemporal_load(a + o + u * 64);
+            y[u] = __builtin_nontemporal_load(b + o + u * 64);
+            z[u] = __builtin_nontemporal_load(c + o + u * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            x[u] = x[u] * 1.0001f + y[u] * 0.001f; y[u] = y[u] * 0.9f + z[u]; z[u] = z[u] * 0.999f + x[u];
+            __builtin_nontemporal_store(x[u], a2 + o + u * 64);
+            __builtin_nontemporal_store(y[u], b2 + o + u * 64);
+            __builtin_nontemporal_store(z[u], c2 + o + u * 64);
+        }
+    }
+}
+
+// C: out-of-place (ping-pong) variant of A, and a read-only reduction
+template <int NT>
+__global__ __launch_bounds__(256) void k_oop(const f32x4* a, const f32x4* b, const f32x4* c, f32x4* a2, f32x4* b2, f32x4* c2, size_t n4) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    for (; i < n4; i += st) {
+        f32x4 x = NT ? __builtin_nontemporal_load(a + i) : a[i];
+        f32x4 y = NT ? __builtin_nontemporal_load(b + i) : b[i];
+        f32x4 z = NT ? __builtin_nontemporal_load(c + i) : c[i];
+        x = x * 1.0001f + y * 0.001f; y = y * 0.9f + z; z = z * 0.999f + x;
+        if (NT) { __builtin_nontemporal_store(x, a2 + i); __builtin_nontemporal_store(y, b2 + i); __builtin_nontemporal_store(z, c2 + i); }
+        else { a2[i] = x; b2[i] = y; c2[i] = z; }
+    }
+}
+template <int NT>
+__global__ __launch_bounds__(256) void k_read(const f32x4* a, size_t n4, float* out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    f32x4 acc = {0, 0, 0, 0};
+    for (; i + 3 * st < n4; i += 4 * st) {
+        f32x4 x0 = NT ? __builtin_nontemporal_load(a + i) : a[i];
+        f32x4 x1 = NT ? __builtin_nontemporal_load(a + i + st) : a[i + st];
+        f32x4 x2 = NT ? __builtin_nontemporal_load(a + i + 2 * st) : a[i + 2 * st];
+        f32x4 x3 = NT ? __builtin_nontemporal_load(a + i + 3 * st) : a[i + 3 * st];
+        acc += x0 + x1 + x2 + x3;
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) out[0] = 1.f;
+}
+
+template <typename F>
+float timeit(F f, int reps = 10) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f(); hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int i = 0; i < reps; ++i) f();
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms / reps;
+}
+
+#include <algorithm>
+#include <functional>
+#include <string>
+int main() {
+    const size_t n = 128ull * 1000 * 1000;  // floats per array (512 MB), like C4's wide kernels
+    float *a, *b, *c, *a2, *b2, *c2, *o;
+    hipMalloc(&a, n * 4); hipMalloc(&b, n * 4); hipMalloc(&c, n * 4);
+    hipMalloc(&a2, n * 4); hipMalloc(&b2, n * 4); hipMalloc(&c2, n * 4); hipMalloc(&o, 64);
+    for (float* p : {a, b, c, a2, b2, c2}) hipMemset(p, 0, n * 4);
+    f32x4 *A = (f32x4*)a, *B = (f32x4*)b, *C = (f32x4*)c, *A2 = (f32x4*)a2, *B2 = (f32x4*)b2, *C2 = (f32x4*)c2;
+    const size_t n4 = n / 4;
+    struct V { std::string name; std::function<void()> f; int narr; std::vector<float> ms; };
+    std::vector<V> vs;
+    for (int g : {512, 1024, 2048}) {
+        vs.push_back({"inplace stride 3arr g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_stride<3, 0>), dim3(g), dim3(256), 0, 0, A, B, C, n4); }, 3, {}});
+        vs.push_back({"inplace stride 3arr nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_stride<3, 1>), dim3(g), dim3(256), 0, 0, A, B, C, n4); }, 3, {}});
+        vs.push_back({"oop stride 3arr g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_oop<0>), dim3(g), dim3(256), 0, 0, A, B, C, A2, B2, C2, n4); }, 3, {}});
+        vs.push_back({"oop stride 3arr nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_oop<1>), dim3(g), dim3(256), 0, 0, A, B, C, A2, B2, C2, n4); }, 3, {}});
+    }
+    for (int g : {512, 768, 1024}) {
+        vs.push_back({"inplace chunk16 contiguous g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk<3, 16, 0>), dim3(g), dim3(256), 0, 0, A, B, C, n4 / (16 * 64)); }, 3, {}});
+        vs.push_back({"inplace chunk16 nt contiguous g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk<3, 16, 1>), dim3(g), dim3(256), 0, 0, A, B, C, n4 / (16 * 64)); }, 3, {}});
+        vs.push_back({"oop chunk16 nt contiguous g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk_oop<16, 0>), dim3(g), dim3(256), 0, 0, A, B, C, A2, B2, C2, n4 / (16 * 64)); }, 3, {}});
+        vs.push_back({"oop chunk16 nt round-robin g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk_oop<16, 1>), dim3(g), dim3(256), 0, 0, A, B, C, A2, B2, C2, n4 / (16 * 64)); }, 3, {}});
+        vs.push_back({"oop chunk4 nt round-robin g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk_oop<4, 1>), dim3(g), dim3(256), 0, 0, A, B, C, A2, B2, C2, n4 / (4 * 64)); }, 3, {}});
+    }
+    for (int g : {512, 1024}) {
+        vs.push_back({"read-only g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_read<0>), dim3(g), dim3(256), 0, 0, A, n4, o); }, 0, {}});
+        vs.push_back({"read-only nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_read<1>), dim3(g), dim3(256), 0, 0, A, n4, o); }, 0, {}});
+    }
+    for (int round = 0; round < 7; ++round)
+        for (auto& v : vs) v.ms.push_back(timeit(v.f, 3));
+    for (auto& v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        const double bytes = v.narr ? v.narr * 2.0 * n * 4 : 1.0 * n * 4;
+        printf("%-40s median %7.1f us (%5.0f GB/s)  min %7.1f us (%5.0f GB/s)  max %7.1f\n", v.name.c_str(), v.ms[3] * 1e3,
+               bytes / (v.ms[3] * 1e-3) / 1e9, v.ms[0] * 1e3, bytes / (v.ms[0] * 1e-3) / 1e9, v.ms[6] * 1e3);
+    }
+    return 0;
+}
