@@ -214,6 +214,9 @@ size_t lds_dense_fwd(int K) { return (size_t)(32 * (K + 1) + 4096) * 4; }
 size_t lds_dense_bwd(int N) { return (size_t)(2 * 32 * (N + 1) + 4096) * 4; }
 size_t lds_dec(int NWB) { return (size_t)(32 * (NWB * 32 + 1) + 4 * 3 * 32 * 33) * 4; }
 size_t lds_enc_bwd(int Wp) { return (size_t)32 * Wp * 4; }
+size_t lds_dec_grp(int ngrp) {
+    return std::max<size_t>((size_t)32 * (ngrp * 128 + 1) + 8 * 2 * 32 * 33, (size_t)8 * 4 * 1024 + 8) * 4;
+}
 size_t lds_enc_fwd(int NWB) { return (size_t)4 * NWB * 1024 * 4; }
 
 template <typename Kern>
@@ -243,6 +246,13 @@ int setup_kernel_attrs(pvae_engine* e) {
         default: PV_ATTR(4) break;
     }
 #undef PV_ATTR
+#define PV_ATTR_G(G)                                                                  \
+    HIPCHK(allow_lds(pvk_dec_grp<G, 1, PV_MODE_TRAIN>, lds_dec_grp(G)));              \
+    HIPCHK(allow_lds(pvk_dec_grp<G, 1, PV_MODE_GRAD>, lds_dec_grp(G)));               \
+    HIPCHK(allow_lds(pvk_dec_grp<G, 0, PV_MODE_TRAIN>, lds_dec_grp(G)));
+    if (e->ngrp == 2) { PV_ATTR_G(2) }
+    if (e->ngrp == 4) { PV_ATTR_G(4) }
+#undef PV_ATTR_G
     return 0;
 }
 
@@ -299,7 +309,7 @@ int stage_a(pvae_engine* e, int row_offset, bool need_xt) {
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_enc_fwd<N_>, dim3(e->enc_wgs), dim3(256), lds_enc_fwd(N_), e->stream, e->W1.w, e->geno,
                                               e->row_bytes, e->d_rows, e->st, row_offset, e->nblk, e->ngrp, e->encpart));
         if ((rc = launch_check(e, "enc_fwd"))) return rc;
-        hipLaunchKernelGGL(pvk_reduce_parts, dim3(32 * e->Wp / 64), dim3(256), 0, e->stream, e->encpart, e->enc_wgs, 32 * e->Wp,
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(32 * e->Wp / 64), dim3(256), 0, e->stream, e->encpart, e->enc_wgs / e->ngrp, 32 * e->Wp,
                            0.5f, e->P, (const float*)nullptr, (float*)nullptr);
         if ((rc = launch_check(e, "enc_reduce"))) return rc;
     }
@@ -409,6 +419,28 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
             if ((rc = allocf(e, &e->Vout.g, e->Vout.n))) return rc;
             if ((rc = allocf(e, &e->cout.g, e->cout.n))) return rc;
         }
+        if (e->ngrp > 1) {
+#define PV_DEC_G(G, TR, MD, V_, M_, VV_, V2_, M2_, VV2_, C_, MC_, VC_)                                                    \
+    hipLaunchKernelGGL((pvk_dec_grp<G, TR, MD>), dim3(e->dec_wgs), dim3(512), lds_dec_grp(G), e->stream, V_, M_, VV_, V2_, M2_, \
+                       VV2_, C_, MC_, VC_, gD, e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart, e->losspart)
+#define PV_DEC_GG(TR, MD, ...)                                  \
+    do {                                                        \
+        if (e->ngrp == 2) PV_DEC_G(2, TR, MD, __VA_ARGS__);     \
+        else PV_DEC_G(4, TR, MD, __VA_ARGS__);                  \
+    } while (0)
+            float* nul = nullptr;
+            if (mode == 0) {
+                PV_DEC_GG(1, PV_MODE_TRAIN, e->Vout.w, e->Vout.m, e->Vout.v, e->Vout.w2, e->Vout.m2, e->Vout.v2, e->cout.w,
+                          e->cout.m, e->cout.v);
+                e->Vout.swap();
+            } else if (mode == 2) {
+                PV_DEC_GG(1, PV_MODE_GRAD, e->Vout.w, nul, nul, nul, e->Vout.g, nul, e->cout.w, e->cout.g, nul);
+            } else {
+                PV_DEC_GG(0, PV_MODE_TRAIN, e->Vout.w, nul, nul, nul, nul, nul, e->cout.w, nul, nul);
+            }
+#undef PV_DEC_GG
+#undef PV_DEC_G
+        } else
         if (mode == 0) {
             PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 1, PV_MODE_TRAIN>), dim3(e->dec_wgs), dim3(256), lds_dec(N_),
                                                   e->stream, e->Vout.w, e->Vout.m, e->Vout.v, e->Vout.w2, e->Vout.m2,
@@ -709,7 +741,7 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
         return bail(set_err(e, -2, "bad dimensions"));
     if (cfg->batch_size < 1 || cfg->batch_size > 32)
         return bail(set_err(e, -2, "batch_size %d unsupported: this build handles 1..32 rows per step", cfg->batch_size));
-    if (cfg->width > 128) return bail(set_err(e, -2, "width %d unsupported: this build handles widths up to 128", cfg->width));
+    if (cfg->width > 512) return bail(set_err(e, -2, "width %d unsupported: this build handles widths up to 512", cfg->width));
     if (cfg->latent_dim > 16) return bail(set_err(e, -2, "latent_dim %d unsupported (max 16)", cfg->latent_dim));
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -725,9 +757,10 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     e->nblk = (int)((e->L + 31) / 32);
     e->Lp = (int64_t)e->nblk * 32;
     e->W = cfg->width;
-    e->Wp = pad32(e->W);
-    e->NWB = e->Wp / 32;
-    e->ngrp = 1;
+    // widths above 128 are cut into groups of 128 units (padded to 256 or 512)
+    e->Wp = e->W <= 128 ? pad32(e->W) : (e->W <= 256 ? 256 : 512);
+    e->NWB = e->Wp <= 128 ? e->Wp / 32 : 4;
+    e->ngrp = e->Wp <= 128 ? 1 : e->Wp / 128;
     e->D = cfg->depth;
     e->K = cfg->latent_dim;
     e->Kh = pad32(2 * e->K);
@@ -792,6 +825,7 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
 
     const int64_t tasks = (int64_t)e->nblk * e->ngrp;
     auto clampi = [](int64_t v, int64_t lo, int64_t hi) { return (int)std::min(hi, std::max(lo, v)); };
+    CK(setup_kernel_attrs(e));
     // the wide kernels are persistent-style: the grid is exactly what is co-resident (CUs x blocks per CU), so that
     // every wave streams the same number of subtiles and there is no second, partly filled round
     {
@@ -801,14 +835,19 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
         int o_enc = 1, o_dec = 1, o_encb = 1;
         PV_DISPATCH_NWB(e, {
             HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_enc, pvk_enc_fwd<N_>, 256, lds_enc_fwd(N_)));
-            HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, pvk_dec<N_, 1, PV_MODE_TRAIN>, 256, lds_dec(N_)));
+            if (e->ngrp == 1)
+                HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, pvk_dec<N_, 1, PV_MODE_TRAIN>, 256, lds_dec(N_)));
+            else if (e->ngrp == 2)
+                HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, pvk_dec_grp<2, 1, PV_MODE_TRAIN>, 512, lds_dec_grp(2)));
+            else
+                HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, pvk_dec_grp<4, 1, PV_MODE_TRAIN>, 512, lds_dec_grp(4)));
             HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_encb, pvk_enc_bwd<N_, PV_MODE_TRAIN>, 256, lds_enc_bwd(e->Wp)));
         });
         auto envi = [](const char* k, int dflt) { const char* v = getenv(k); return v && *v ? atoi(v) : dflt; };
         o_enc = envi("PVAE_ENC_OCC", std::min(std::max(o_enc, 1), 2));
         o_dec = envi("PVAE_DEC_OCC", std::max(o_dec, 1));
         o_encb = envi("PVAE_ENCB_OCC", std::max(o_encb, 1));
-        e->enc_wgs = clampi((tasks + 3) / 4, 1, (int64_t)cus * o_enc);
+        e->enc_wgs = clampi((e->nblk + 3) / 4, 1, (int64_t)cus * o_enc / e->ngrp) * e->ngrp;  // multiple of ngrp
         e->dec_wgs = clampi((e->nblk + 3) / 4, 1, (int64_t)cus * o_dec);
         e->encb_wgs = clampi((tasks + 3) / 4, 1, (int64_t)cus * o_encb);
         if (getenv("PVAE_VERBOSE"))
@@ -828,7 +867,6 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     HK(hipMemset(e->d_counter, 0, sizeof(uint64_t)));
     CK(ensure_rows(e, 4096));
     CK(ensure_loss(e, 1024));
-    CK(setup_kernel_attrs(e));
     e->fused_narrow = e->Wp <= 128 && 2 * e->D + 2 <= PVN_MAXOPS && !getenv("PVAE_NO_FUSED_NARROW");
     if (e->fused_narrow) {
         CK(build_fwd_ops(e));

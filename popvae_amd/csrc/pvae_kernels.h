@@ -131,9 +131,10 @@ __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1,
                                                    const PvStep* st, int row_offset, int nblk, int ngrp,
                                                    float* __restrict__ part) {
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 4;
-    const int grp = gw % ngrp, slot = gw / ngrp, nslots = nwaves / ngrp;
+    // all 4 waves of a workgroup work on the same group of 128 units (their fragments are summed below);
+    // gridDim.x is a multiple of ngrp
+    const int grp = blockIdx.x % ngrp, slot = (blockIdx.x / ngrp) * 4 + (threadIdx.x >> 6);
+    const int nslots = (gridDim.x / ngrp) * 4;
     const int per = (nblk + nslots - 1) / nslots;
     const int blk0 = slot * per;
     int blk1 = blk0 + per;
@@ -176,11 +177,13 @@ __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1,
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[((wave * NWB + w) * 16 + r) * 64 + lane] = acc[w][r];
     __syncthreads();
-    float* p = part + (int64_t)blockIdx.x * (NWB * 1024);
+    // part[blockIdx.x / ngrp][b][Wp]: this workgroup fills the columns of its group
+    const int ldp = ngrp * NWB * 32;
+    float* p = part + (int64_t)(blockIdx.x / ngrp) * (32 * ldp) + grp * (NWB * 32);
     for (int e = threadIdx.x; e < NWB * 1024; e += 256) {
         const float sum = ((red[e] + red[NWB * 1024 + e]) + red[2 * NWB * 1024 + e]) + red[3 * NWB * 1024 + e];
         const int w = e >> 10, r = (e >> 6) & 15, ln = e & 63;
-        p[PV_ROW(r, ln >> 5) * (NWB * 32) + w * 32 + (ln & 31)] = sum;
+        p[PV_ROW(r, ln >> 5) * ldp + w * 32 + (ln & 31)] = sum;
     }
 }
 
@@ -611,6 +614,220 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
             const float s = ((red[e] + red[NWB * 1024 + e]) + red[2 * NWB * 1024 + e]) + red[3 * NWB * 1024 + e];
             const int w = e >> 10, r = (e >> 6) & 15, ln = e & 63;
             dgpart[(int64_t)blockIdx.x * (32 * WP) + PV_ROW(r, ln >> 5) * WP + w * 32 + (ln & 31)] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wide decoder for widths above 128 (NGRP = Wp / 128 groups of 128 units, NGRP in {2, 4}).
+// Workgroup = 8 waves; wave = (block bsub = wave / NGRP, group grp = wave % NGRP), i.e. 8 / NGRP SNP blocks
+// per iteration.  Each wave forms the partial logits of its group; the partials meet in LDS (the wave's own
+// V^T staging area doubles as the mailbox) and every wave of a block sums them in group order, so all of
+// them hold bit-identical logits.  From there on each wave treats its group as pvk_dec does: dg partial,
+// dV + Adam on its own 32x128 subtile, which it still holds in registers -- no weight byte is read twice.
+// ---------------------------------------------------------------------------------------------
+template <int NGRP, int TRAIN, int MODE>
+__global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, const float* __restrict__ mV,
+                                                   const float* __restrict__ vV, float* __restrict__ V2,
+                                                   float* __restrict__ mV2, float* __restrict__ vV2,
+                                                   float* __restrict__ cb, float* __restrict__ mC, float* __restrict__ vC,
+                                                   const float* __restrict__ g, const uint64_t* __restrict__ Xt,
+                                                   int nblk, int L, const PvStep* st, PvAdam adam,
+                                                   float* __restrict__ dgpart, float* __restrict__ losspart) {
+    constexpr int NWB = 4;
+    constexpr int WP = NGRP * 128;
+    constexpr int LDG = WP + 1;
+    constexpr int BPI = 8 / NGRP;  // SNP blocks per workgroup iteration
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* g_s = smem;  // [32][LDG]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    float* vt = smem + 32 * LDG + wave * (2 * 32 * 33);  // [32][33]; also this wave's partial-logit mailbox
+    float* dt = vt + 32 * 33;                            // [32][33]
+    const int grp = wave % NGRP, bsub = wave / NGRP;
+    const int bgroups = (nblk + BPI - 1) / BPI;
+    const int per = (bgroups + gridDim.x - 1) / gridDim.x;
+    const int nrows = st->nrows;
+    const float inv_b = st->inv_b, alpha = st->alpha;
+
+    for (int i = tid; i < 32 * WP; i += 512) g_s[(i / WP) * LDG + (i % WP)] = g[i];
+    __syncthreads();
+    const float* gg = g_s + grp * 128;  // this wave's 128 units
+
+    f32x16 dg[NWB];
+    float lossacc = 0.f;
+    if (TRAIN) {
+#pragma unroll
+        for (int w = 0; w < NWB; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dg[w][r] = 0.f;
+    }
+
+    for (int it = 0; it < per; ++it) {
+        asm volatile("" ::: "memory");
+        const int bg = blockIdx.x * per + it;
+        const int blk = bg * BPI + bsub;
+        const bool valid = bg < bgroups && blk < nblk;  // wave-uniform; invalid waves only keep the barriers
+        const int64_t tbase = ((int64_t)blk * NGRP + grp) * (NWB * 256);  // in f32x4 units
+        const f32x4* tV = reinterpret_cast<const f32x4*>(V) + tbase;
+        f32x4 vv[NWB][4];
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+        if (valid) {
+#pragma unroll
+            for (int w = 0; w < NWB; ++w)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vv[w][q] = __builtin_nontemporal_load(tV + (w * 4 + q) * 64 + lane);
+            // (1) partial logits over this group's units
+#pragma unroll
+            for (int w = 0; w < NWB; ++w)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ga = gg[c * LDG + w * 32 + PV_ROW(r, h)];
+                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, vv[w][r >> 2][r & 3], a, 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vt[r * 64 + lane] = a[r];
+        __syncthreads();
+        {
+            const float* mb = smem + 32 * LDG + (bsub * NGRP) * (2 * 32 * 33);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sum = mb[r * 64 + lane];
+#pragma unroll
+                for (int g2 = 1; g2 < NGRP; ++g2) sum += mb[g2 * (2 * 32 * 33) + r * 64 + lane];
+                a[r] = sum;
+            }
+        }
+        __syncthreads();
+        if (!valid) continue;
+        const int l = blk * 32 + c;
+        const bool lvalid = l < L;
+        const float bias = cb[l];
+        uint64_t xw = Xt[l] >> (8 * h);
+        const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
+        // (2) sigmoid / BCE-from-logits / dlogits (every wave of the block computes the same values)
+        float dbias = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = PV_ROW(r, h);
+            const float x = 0.5f * pv_code(lo, hi, r);
+            const float z = a[r] + bias;
+            const float e = __expf(-fabsf(z));
+            const float bce = fmaxf(z, 0.f) - z * x + __logf(1.f + e);
+            const float inv = __builtin_amdgcn_rcpf(1.f + e);
+            const float p = z >= 0.f ? inv : e * inv;
+            const bool ok = lvalid && (b < nrows);
+            lossacc += (ok && grp == 0) ? bce : 0.f;
+            const float d = ok ? (p - x) * inv_b : 0.f;
+            a[r] = d;
+            dbias += d;
+        }
+        if (TRAIN) {
+            dbias += __shfl_xor(dbias, 32);
+            if (grp == 0 && h == 0 && lvalid) {
+                if (MODE == PV_MODE_GRAD) {
+                    mC[l] = dbias;
+                } else {
+                    float w_ = bias, m_ = mC[l], v_ = vC[l];
+                    pv_adam(w_, m_, v_, dbias, alpha, adam);
+                    cb[l] = w_;
+                    mC[l] = m_;
+                    vC[l] = v_;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dt[PV_ROW(r, h) * 33 + c] = a[r];
+            // (3) dg[b][unit] += sum_l da[b][l] * V[unit][l]
+#pragma unroll
+            for (int w = 0; w < NWB; ++w) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vt[PV_ROW(r, h) * 33 + c] = vv[w][r >> 2][r & 3];
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float av = dt[c * 33 + PV_ROW(r, h)];
+                    const float bv = vt[c * 33 + PV_ROW(r, h)];
+                    dg[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, dg[w], 0, 0, 0);
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // (4) dV[unit][l] = sum_b g[b][unit] * da[b][l], then Adam
+            const f32x4* tM = reinterpret_cast<const f32x4*>(mV) + tbase;
+            const f32x4* tVv = reinterpret_cast<const f32x4*>(vV) + tbase;
+            f32x4* dV2 = reinterpret_cast<f32x4*>(V2) + tbase;
+            f32x4* dM2 = reinterpret_cast<f32x4*>(mV2) + tbase;
+            f32x4* dVv2 = reinterpret_cast<f32x4*>(vV2) + tbase;
+#pragma unroll
+            for (int w = 0; w < NWB; ++w) {
+                f32x16 dv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dv[r] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ga = gg[PV_ROW(r, h) * LDG + w * 32 + c];
+                    dv = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, a[r], dv, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int off = (w * 4 + q) * 64 + lane;
+                    if (MODE == PV_MODE_GRAD) {
+                        f32x4 gq = {dv[q * 4 + 0], dv[q * 4 + 1], dv[q * 4 + 2], dv[q * 4 + 3]};
+                        dM2[off] = gq;
+                    } else {
+                        f32x4 wq = vv[w][q], mq = __builtin_nontemporal_load(tM + off), vq = __builtin_nontemporal_load(tVv + off);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float w_ = wq[e], m_ = mq[e], v_ = vq[e];
+                            pv_adam(w_, m_, v_, dv[q * 4 + e], alpha, adam);
+                            wq[e] = w_;
+                            mq[e] = m_;
+                            vq[e] = v_;
+                        }
+                        __builtin_nontemporal_store(wq, dV2 + off);
+                        __builtin_nontemporal_store(mq, dM2 + off);
+                        __builtin_nontemporal_store(vq, dVv2 + off);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // ---- per-workgroup reductions (fixed order) ----
+    __syncthreads();
+    float* red = smem;  // [8 waves][NWB*16][64], then [8] loss
+    lossacc += __shfl_xor(lossacc, 1);
+    lossacc += __shfl_xor(lossacc, 2);
+    lossacc += __shfl_xor(lossacc, 4);
+    lossacc += __shfl_xor(lossacc, 8);
+    lossacc += __shfl_xor(lossacc, 16);
+    lossacc += __shfl_xor(lossacc, 32);
+    float* lred = red + 8 * NWB * 1024;
+    if (lane == 0) lred[wave] = lossacc;
+    if (TRAIN) {
+#pragma unroll
+        for (int w = 0; w < NWB; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave * NWB + w) * 16 + r) * 64 + lane] = dg[w][r];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float sacc = 0.f;
+        for (int w2 = 0; w2 < 8; ++w2) sacc += lred[w2];
+        losspart[blockIdx.x] = sacc;
+    }
+    if (TRAIN) {
+        for (int e = tid; e < NGRP * NWB * 1024; e += 512) {
+            const int gq = e / (NWB * 1024), f = e % (NWB * 1024);
+            float sum = red[(0 * NGRP + gq) * (NWB * 1024) + f];
+#pragma unroll
+            for (int b2 = 1; b2 < BPI; ++b2) sum += red[(b2 * NGRP + gq) * (NWB * 1024) + f];
+            const int w = f >> 10, r = (f >> 6) & 15, ln = f & 63;
+            dgpart[(int64_t)blockIdx.x * (32 * WP) + PV_ROW(r, ln >> 5) * WP + gq * 128 + w * 32 + (ln & 31)] = sum;
         }
     }
 }

@@ -43,6 +43,9 @@ CASES = [
     (40, 777, 64, 3, 3, 7),        # ragged L, W = 64, K = 3
     (40, 300, 100, 2, 5, 32),      # width padded 100 -> 128
     (33, 31, 32, 1, 1, 1),         # L < one block, depth 1, single row
+    (40, 700, 256, 3, 2, 32),      # two groups of 128 units (grouped wide decoder, per-layer narrow kernels)
+    (40, 1000, 512, 2, 2, 19),     # four groups, short batch (C3 / grid-search width)
+    (40, 500, 200, 2, 3, 32),      # width 200 padded to 256
 ]
 
 
@@ -80,7 +83,7 @@ def test_weight_roundtrip_and_layouts():
     e.close()
 
 
-@pytest.mark.parametrize("L,W,D", [(1000, 128, 3), (3887, 128, 6)])
+@pytest.mark.parametrize("L,W,D", [(1000, 128, 3), (3887, 128, 6), (900, 256, 3), (700, 512, 2)])
 def test_adam_training_steps_match_oracle(L, W, D):
     """Five fused-Adam train steps (incl. a short batch) vs oracle float64 Keras-Adam."""
     N, K = 64, 2

@@ -10,7 +10,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from popvae_amd import engine as E  # noqa: E402
 
-SH = {"C4": (2504, 1_000_000, 128, 6), "C2": (1000, 100_000, 128, 6), "C1": (95, 3887, 128, 6)}
+SH = {"C4": (2504, 1_000_000, 128, 6), "C2": (1000, 100_000, 128, 6), "C1": (95, 3887, 128, 6),
+      "C3": (929, 500_000, 512, 6), "C5a": (1000, 200_000, 256, 5), "C5b": (1000, 200_000, 32, 3)}
 name = sys.argv[1] if len(sys.argv) > 1 else "C4"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 N, L, W, D = SH[name]
@@ -27,13 +28,15 @@ if L % 32:
 e = E.Engine(n_snps=L, width=W, depth=D, latent_dim=2, batch_size=32, seed=1)
 e.load_genotypes(packed)
 e.init_weights(1)
+if os.environ.get("LR"):
+    e.lr = float(os.environ["LR"])
 rows = np.concatenate([g.permutation(N) for _ in range(steps * 32 // N + 2)])[:steps * 32].astype(np.int32)
 e.train_epoch(rows[:5 * 32], np.zeros(0, np.int32))
 e.set_timing(True)
 t0 = time.perf_counter()
 loss, _ = e.train_epoch(rows, np.zeros(0, np.int32))
 dt = time.perf_counter() - t0
-Wp = (W + 31) // 32 * 32
+Wp = (W + 31) // 32 * 32 if W <= 128 else (256 if W <= 256 else 512)
 algo = {"dec": 24 * L * Wp + 32 * L, "enc_fwd": 4 * L * Wp + 8 * L, "enc_bwd": 24 * L * Wp + 8 * L}
 print(f"{name}: {dt / steps * 1e3:.3f} ms/step  {steps * 32 / dt:.0f} samples/s  loss {loss:.3f}")
 tot = 0
