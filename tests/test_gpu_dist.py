@@ -1,0 +1,20 @@
+"""Two ranks sharing the one GPU of the test box (gloo moves the exchange buffers): the real engine's staged
+C-ABI entry points (pvae_stage_a/b/c, pvae_exchange_buffer, pvae_stage_encode) under SNP sharding, against the
+unsharded oracle.  RCCL itself needs one GPU per rank and is exercised by bench.py --gpus N."""
+import numpy as np
+import pytest
+
+from tests import dist_helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dims", [(40, 1000, 128, 3, 2), (40, 700, 256, 2, 2)])
+def test_two_rank_snp_sharding_on_one_gpu(tmp_path, dims):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "res")
+    port = 29500 + int(np.random.default_rng().integers(0, 2000))
+    mp.spawn(H.sharded_worker, args=(2, port, out, True, dims), nprocs=2, join=True)
+    res = [np.load(out + f".{r}.npy", allow_pickle=True)[0] for r in range(2)]
+    ref = H.reference_run(dims)
+    H.compare(res, ref, dims, rtol=1e-4, wtol=2e-2 * 4e-3)
