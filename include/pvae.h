@@ -47,8 +47,10 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out);
 /* K.clear_session() -- popvae.py:369 */
 int pvae_destroy(pvae_engine* e);
 const char* pvae_last_error(pvae_engine* e);
-/* run all engine work on this hipStream_t (pass torch's current stream); NULL = the engine's own stream */
-int pvae_set_stream(pvae_engine* e, void* hip_stream);
+/* run all engine work on this hipStream_t (e.g. torch's current stream, so that a torch.distributed all-reduce
+ * on the exchange buffers is ordered with the stages); hip_stream == NULL is the legacy default stream.
+ * use_own != 0 returns to the engine's own non-blocking stream (the state after pvae_create). */
+int pvae_set_stream(pvae_engine* e, void* hip_stream, int use_own);
 int pvae_synchronize(pvae_engine* e);
 
 /* genotype matrix: traingen/testgen/dc (popvae.py:237-238,259-267) as ONE resident 2-bit matrix of all N

@@ -83,7 +83,7 @@ struct pvae_engine {
     float *encpart = nullptr, *dgpart = nullptr, *losspart = nullptr;
     int enc_wgs = 0, dec_wgs = 0, encb_wgs = 0;
     // fused narrow stack (width <= 128): op tables in device memory
-    bool fused_narrow = false;
+    bool fused_narrow = false, narrow_warm = true, fuse_fwd = false;
     PvFwdOp* d_fwd_ops = nullptr;
     PvBwdOp *d_bwd_ops = nullptr, *d_bwd_ops_grad = nullptr;
     std::vector<float*> dpre_bufs;  // per narrow dense layer, [32][nout]
@@ -138,9 +138,11 @@ int alloc3(pvae_engine* e, Buf3& b, int64_t n) {
     HIPCHK(hipMalloc(&b.w, n * sizeof(float)));
     HIPCHK(hipMalloc(&b.m, n * sizeof(float)));
     HIPCHK(hipMalloc(&b.v, n * sizeof(float)));
-    HIPCHK(hipMemset(b.w, 0, n * sizeof(float)));
-    HIPCHK(hipMemset(b.m, 0, n * sizeof(float)));
-    HIPCHK(hipMemset(b.v, 0, n * sizeof(float)));
+    // zero-fills are issued on the engine's stream: a null-stream hipMemset is not ordered against a
+    // non-blocking stream and could land after a kernel has already written the buffer
+    HIPCHK(hipMemsetAsync(b.w, 0, n * sizeof(float), e->stream));
+    HIPCHK(hipMemsetAsync(b.m, 0, n * sizeof(float), e->stream));
+    HIPCHK(hipMemsetAsync(b.v, 0, n * sizeof(float), e->stream));
     return 0;
 }
 int alloc_pingpong(pvae_engine* e, Buf3& b) {
@@ -156,7 +158,7 @@ void free3(Buf3& b) {
 }
 int allocf(pvae_engine* e, float** p, int64_t n) {
     HIPCHK(hipMalloc(p, n * sizeof(float)));
-    HIPCHK(hipMemset(*p, 0, n * sizeof(float)));
+    HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(float), e->stream));
     return 0;
 }
 int alloc_dense(pvae_engine* e, Dense& d, int kin, int nout, int act) {
@@ -214,6 +216,7 @@ size_t lds_dense_fwd(int K) { return (size_t)(32 * (K + 1) + 4096) * 4; }
 size_t lds_dense_bwd(int N) { return (size_t)(2 * 32 * (N + 1) + 4096) * 4; }
 size_t lds_dec(int NWB) { return (size_t)(32 * (NWB * 32 + 1) + 4 * 3 * 32 * 33) * 4; }
 size_t lds_enc_bwd(int Wp) { return (size_t)32 * Wp * 4; }
+size_t lds_enc_bwd_fused(int NWB) { return std::max<size_t>((size_t)32 * NWB * 32 * 4, (size_t)4 * NWB * 1024 * 4); }
 size_t lds_dec_grp(int ngrp) {
     return std::max<size_t>((size_t)32 * (ngrp * 128 + 1) + 8 * 2 * 32 * 33, (size_t)8 * 4 * 1024 + 8) * 4;
 }
@@ -237,8 +240,9 @@ int setup_kernel_attrs(pvae_engine* e) {
     HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_TRAIN>, lds_dec(N)));                      \
     HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_GRAD>, lds_dec(N)));                       \
     HIPCHK(allow_lds(pvk_dec<N, 0, PV_MODE_TRAIN>, lds_dec(N)));                      \
-    HIPCHK(allow_lds(pvk_enc_bwd<N, PV_MODE_TRAIN>, lds_enc_bwd(e->Wp)));             \
-    HIPCHK(allow_lds(pvk_enc_bwd<N, PV_MODE_GRAD>, lds_enc_bwd(e->Wp)));
+    HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN, 0>), lds_enc_bwd(e->Wp)));        \
+    HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN, 1>), lds_enc_bwd_fused(N)));      \
+    HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_GRAD, 0>), lds_enc_bwd(e->Wp)));
     switch (e->NWB) {
         case 1: PV_ATTR(1) break;
         case 2: PV_ATTR(2) break;
@@ -294,7 +298,7 @@ int run_dense_bwd(pvae_engine* e, Dense& d, const float* in, const float* Y, con
 }
 
 // stage A: batch gather/transposes + partial wide-encoder sums -> P (pre-bias, this rank's SNPs only)
-int stage_a(pvae_engine* e, int row_offset, bool need_xt) {
+int stage_a(pvae_engine* e, int row_offset, bool need_xt, bool fwd_done = false) {
     int rc;
     if (!e->geno) return set_err(e, -3, "no genotypes loaded (pvae_load_genotypes)");
     if (need_xt) {
@@ -304,7 +308,12 @@ int stage_a(pvae_engine* e, int row_offset, bool need_xt) {
                            e->d_rows, e->st, row_offset, e->nblk, e->Xt);
         if ((rc = launch_check(e, "gather_transpose"))) return rc;
     }
-    {
+    if (fwd_done) {
+        // the previous step's pvk_enc_bwd<.., FUSE = 1> already left this batch's partial sums in encpart
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(32 * e->Wp / 64), dim3(256), 0, e->stream, e->encpart, e->encb_wgs, 32 * e->Wp,
+                           0.5f, e->P, (const float*)nullptr, (float*)nullptr);
+        if ((rc = launch_check(e, "enc_reduce"))) return rc;
+    } else {
         Timer t(e, C_ENC_FWD);
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_enc_fwd<N_>, dim3(e->enc_wgs), dim3(256), lds_enc_fwd(N_), e->stream, e->W1.w, e->geno,
                                               e->row_bytes, e->d_rows, e->st, row_offset, e->nblk, e->ngrp, e->encpart));
@@ -362,7 +371,7 @@ int build_fwd_ops(pvae_engine* e) {
     ops.push_back(PvFwdOp{nullptr, e->b1.w, e->h[0], 0, e->Wp, PV_ACT_ELU, PVN_BIAS_ACT});
     for (int i = 0; i < D - 1; ++i) dense(e->enc[i], e->h[i + 1]);
     dense(e->heads, e->headout);
-    ops.push_back(PvFwdOp{nullptr, nullptr, nullptr, e->Kh, e->Kz, PV_ACT_LINEAR, PVN_REPARAM});
+    ops.push_back(PvFwdOp{nullptr, e->heads.B.w /* dummy, never used */, nullptr, e->Kh, e->Kz, PV_ACT_LINEAR, PVN_REPARAM});
     e->n_enc_ops = (int)ops.size();
     dense(e->dec[0], e->g[0]);
     for (int i = 1; i < D; ++i) dense(e->dec[i], e->g[i]);
@@ -373,8 +382,9 @@ int build_fwd_ops(pvae_engine* e) {
 }
 
 int narrow_fused_fwd(pvae_engine* e, bool encoder_only) {
-    hipLaunchKernelGGL(pvk_narrow_fwd, dim3(1), dim3(PVN_THREADS), pvn_lds_fwd(), e->stream, e->d_fwd_ops,
-                       encoder_only ? e->n_enc_ops : e->n_fwd_ops, e->P, e->eps, e->K, e->Kz, e->z, e->kl);
+    const int nops = encoder_only ? e->n_enc_ops : e->n_fwd_ops;
+    hipLaunchKernelGGL(pvk_narrow_fwd, dim3(e->narrow_warm ? 8 * (nops + 1) : 1), dim3(PVN_THREADS), pvn_lds_fwd(), e->stream,
+                       e->d_fwd_ops, nops, e->P, e->eps, e->K, e->Kz, e->z, e->kl);
     return launch_check(e, "narrow_fwd");
 }
 
@@ -469,26 +479,37 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
     return 0;
 }
 
-int enc_bwd_launch(pvae_engine* e, int km) {
+int enc_bwd_launch(pvae_engine* e, int km, bool fuse = false, int next_off = 0, int next_n = 0) {
     int rc;
     Timer t(e, C_ENC_BWD);
+    const uint8_t* nog = nullptr;
+    const int* nor = nullptr;
+    float* nof = nullptr;
     if (km == PV_MODE_GRAD) {
         if (!e->W1.g && (rc = allocf(e, &e->W1.g, e->W1.n))) return rc;
-        PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_GRAD>), dim3(e->encb_wgs), dim3(256),
+        PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_GRAD, 0>), dim3(e->encb_wgs), dim3(256),
                                               lds_enc_bwd(e->Wp), e->stream, e->W1.w, (float*)nullptr, (float*)nullptr,
                                               (float*)nullptr, e->W1.g, (float*)nullptr, e->dpre1, e->Wp, e->Xt, e->nblk,
-                                              e->ngrp, e->st, e->adam));
+                                              e->ngrp, e->st, e->adam, nog, (int64_t)0, nor, 0, 0, nof));
+    } else if (fuse) {
+        PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 1>), dim3(e->encb_wgs), dim3(256),
+                                              lds_enc_bwd_fused(N_), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
+                                              e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam,
+                                              (const uint8_t*)e->geno, e->row_bytes, (const int*)e->d_rows, next_off, next_n,
+                                              e->encpart));
+        e->W1.swap();
     } else {
-        PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN>), dim3(e->encb_wgs), dim3(256),
+        PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 0>), dim3(e->encb_wgs), dim3(256),
                                               lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
-                                              e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam));
+                                              e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam, nog,
+                                              (int64_t)0, nor, 0, 0, nof));
         e->W1.swap();
     }
     return launch_check(e, "enc_bwd");
 }
 
 // stage C: loss, narrow backward (+Adam), wide encoder backward (+Adam)
-int stage_c(pvae_engine* e, int mode, float* d_out3) {
+int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next_off = 0, int next_n = 0) {
     int rc;
     if (e->fused_narrow) {
         {
@@ -500,13 +521,13 @@ int stage_c(pvae_engine* e, int mode, float* d_out3) {
                 if (rc2) return rc2;
                 if ((rc = build_bwd_ops(e, true, &e->d_bwd_ops_grad))) return rc;
             }
-            hipLaunchKernelGGL(pvk_narrow_bwd<PV_MODE_GRAD>, dim3(1), dim3(PVN_THREADS), pvn_lds_bwd(), e->stream,
+            hipLaunchKernelGGL(pvk_narrow_bwd<PV_MODE_GRAD>, dim3(e->narrow_warm ? 8 * (e->n_bwd_ops + 1) : 1), dim3(PVN_THREADS), pvn_lds_bwd(), e->stream,
                                e->d_bwd_ops_grad, e->n_bwd_ops, e->xch1, e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st,
                                e->adam, d_out3, 1);
             hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_GRAD>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, e->d_bwd_ops_grad,
                                e->st, e->adam);
         } else {
-            hipLaunchKernelGGL(pvk_narrow_bwd<PV_MODE_TRAIN>, dim3(1), dim3(PVN_THREADS), pvn_lds_bwd(), e->stream,
+            hipLaunchKernelGGL(pvk_narrow_bwd<PV_MODE_TRAIN>, dim3(e->narrow_warm && mode == 0 ? 8 * (e->n_bwd_ops + 1) : 1), dim3(PVN_THREADS), pvn_lds_bwd(), e->stream,
                                e->d_bwd_ops, e->n_bwd_ops, e->xch1, e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st,
                                e->adam, d_out3, mode == 0 ? 1 : 0);
             if (mode == 0)
@@ -516,7 +537,7 @@ int stage_c(pvae_engine* e, int mode, float* d_out3) {
         if ((rc = launch_check(e, "narrow_bwd"))) return rc;
         }
         if (mode == 1) return 0;
-        return enc_bwd_launch(e, mode == 2 ? PV_MODE_GRAD : PV_MODE_TRAIN);
+        return enc_bwd_launch(e, mode == 2 ? PV_MODE_GRAD : PV_MODE_TRAIN, fuse, next_off, next_n);
     }
     hipLaunchKernelGGL(pvk_loss_final, dim3(1), dim3(64), 0, e->stream, e->xch1 + 32 * e->Wp, e->kl, e->st, d_out3);
     if ((rc = launch_check(e, "loss_final"))) return rc;
@@ -557,7 +578,7 @@ int stage_c(pvae_engine* e, int mode, float* d_out3) {
         }
         if ((rc = launch_check(e, "bias_bwd"))) return rc;
     }
-    return enc_bwd_launch(e, km);
+    return enc_bwd_launch(e, km, fuse, next_off, next_n);
 }
 
 int ensure_rows(pvae_engine* e, int64_t n) {
@@ -821,7 +842,7 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     CK(allocf(e, &e->dB, act_n));
     CK(allocf(e, &e->dpre1, 32 * e->Wp));
     HK(hipMalloc(&e->Xt, e->Lp * sizeof(uint64_t)));
-    HK(hipMemset(e->Xt, 0, e->Lp * sizeof(uint64_t)));
+    HK(hipMemsetAsync(e->Xt, 0, e->Lp * sizeof(uint64_t), e->stream));
 
     const int64_t tasks = (int64_t)e->nblk * e->ngrp;
     auto clampi = [](int64_t v, int64_t lo, int64_t hi) { return (int)std::min(hi, std::max(lo, v)); };
@@ -841,7 +862,10 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
                 HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, pvk_dec_grp<2, 1, PV_MODE_TRAIN>, 512, lds_dec_grp(2)));
             else
                 HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, pvk_dec_grp<4, 1, PV_MODE_TRAIN>, 512, lds_dec_grp(4)));
-            HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_encb, pvk_enc_bwd<N_, PV_MODE_TRAIN>, 256, lds_enc_bwd(e->Wp)));
+            if (e->ngrp == 1 && !getenv("PVAE_NO_FUSE_FWD"))
+                HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_encb, (pvk_enc_bwd<N_, PV_MODE_TRAIN, 1>), 256, lds_enc_bwd_fused(N_)));
+            else
+                HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_encb, (pvk_enc_bwd<N_, PV_MODE_TRAIN, 0>), 256, lds_enc_bwd(e->Wp)));
         });
         auto envi = [](const char* k, int dflt) { const char* v = getenv(k); return v && *v ? atoi(v) : dflt; };
         o_enc = envi("PVAE_ENC_OCC", std::min(std::max(o_enc, 1), 2));
@@ -854,7 +878,8 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
             fprintf(stderr, "[pvae] CUs %d; blocks/CU enc_fwd %d dec %d enc_bwd %d; grids %d %d %d\n", cus, o_enc, o_dec, o_encb,
                     e->enc_wgs, e->dec_wgs, e->encb_wgs);
     }
-    CK(allocf(e, &e->encpart, (int64_t)e->enc_wgs * e->NWB * 1024));
+    CK(allocf(e, &e->encpart, (int64_t)std::max(e->enc_wgs, e->encb_wgs) * e->NWB * 1024));
+    e->fuse_fwd = e->ngrp == 1 && !getenv("PVAE_NO_FUSE_FWD");
     CK(allocf(e, &e->dgpart, (int64_t)e->dec_wgs * 32 * e->Wp));
     CK(allocf(e, &e->losspart, (int64_t)e->dec_wgs));
 
@@ -864,14 +889,16 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     HK(hipMemcpy(e->st, &st0, sizeof st0, hipMemcpyHostToDevice));
     HK(hipMalloc(&e->d_ntotal, sizeof(int)));
     HK(hipMalloc(&e->d_counter, sizeof(uint64_t)));
-    HK(hipMemset(e->d_counter, 0, sizeof(uint64_t)));
+    HK(hipMemsetAsync(e->d_counter, 0, sizeof(uint64_t), e->stream));
     CK(ensure_rows(e, 4096));
     CK(ensure_loss(e, 1024));
     e->fused_narrow = e->Wp <= 128 && 2 * e->D + 2 <= PVN_MAXOPS && !getenv("PVAE_NO_FUSED_NARROW");
+    e->narrow_warm = !getenv("PVAE_NO_NARROW_WARM");
     if (e->fused_narrow) {
         CK(build_fwd_ops(e));
         CK(build_bwd_ops(e, false, &e->d_bwd_ops));
     }
+    HK(hipStreamSynchronize(e->stream));
 #undef CK
 #undef HK
     *out = e;
@@ -898,9 +925,9 @@ int pvae_destroy(pvae_engine* e) {
     return 0;
 }
 
-int pvae_set_stream(pvae_engine* e, void* s) {
+int pvae_set_stream(pvae_engine* e, void* s, int use_own) {
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->stream = s ? (hipStream_t)s : e->own_stream;
+    e->stream = use_own ? e->own_stream : (hipStream_t)s;  // s == NULL is the legacy default stream
     return 0;
 }
 
@@ -951,11 +978,12 @@ int pvae_reset_optimizer(pvae_engine* e) {
     HIPCHK(hipStreamSynchronize(e->stream));
     int rc = 0;
     for_each_buf(e, [&](Buf3& b) {
-        if (hipMemset(b.m, 0, b.n * 4) != hipSuccess || hipMemset(b.v, 0, b.n * 4) != hipSuccess) rc = -10;
+        if (hipMemsetAsync(b.m, 0, b.n * 4, e->stream) != hipSuccess || hipMemsetAsync(b.v, 0, b.n * 4, e->stream) != hipSuccess) rc = -10;
     });
     if (rc) return set_err(e, rc, "hipMemset failed");
     PvStep st0{};
     st0.lr = e->lr_host;
+    HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(e->st, &st0, sizeof st0, hipMemcpyHostToDevice));
     return 0;
 }
@@ -1022,6 +1050,7 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
     HIPCHK(hipMemcpyAsync(e->d_rows, perm, (size_t)n_train * sizeof(int), hipMemcpyHostToDevice, e->stream));
     if (n_val > 0)
         HIPCHK(hipMemcpyAsync(e->d_rows + n_train, val_rows, (size_t)n_val * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    bool fwd_done = false;
     for (int phase = 0; phase < 2; ++phase) {
         const int steps = phase == 0 ? st_tr : st_va;
         if (!steps) continue;
@@ -1030,13 +1059,22 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
         HIPCHK(hipStreamSynchronize(e->stream));  // nt is a stack variable
         const int base = phase == 0 ? 0 : n_train;
         for (int s = 0; s < steps; ++s) {
+            // the first-layer forward of the NEXT batch rides on this step's wide encoder backward
+            int next_off = 0, next_n = 0;
+            bool fuse = false;
+            if (phase == 0 && e->fuse_fwd) {
+                if (s + 1 < st_tr) { next_off = (s + 1) * B; next_n = std::min(B, n_train - next_off); fuse = true; }
+                else if (st_va > 0) { next_off = n_train; next_n = std::min(B, (int)n_val); fuse = true; }
+            }
             hipLaunchKernelGGL(pvk_step_begin, dim3(1), dim3(64), 0, e->stream, e->st, (const int*)e->d_ntotal, 0, B, s, phase == 0 ? 1 : 0,
                                e->adam.b1, e->adam.b2);
             hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, 32 * e->K, e->cfg.seed, e->d_counter);
             if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
-            if ((rc = stage_a(e, base + s * B, true))) return rc;
+            if ((rc = stage_a(e, base + s * B, true, fwd_done))) return rc;
             if ((rc = stage_b(e, phase == 0 ? 0 : 1))) return rc;
-            if ((rc = stage_c(e, phase == 0 ? 0 : 1, e->d_loss + 3 * ((phase == 0 ? 0 : st_tr) + s)))) return rc;
+            if ((rc = stage_c(e, phase == 0 ? 0 : 1, e->d_loss + 3 * ((phase == 0 ? 0 : st_tr) + s), fuse, next_off, next_n)))
+                return rc;
+            fwd_done = fuse;
         }
     }
     std::vector<float> hl((size_t)(st_tr + st_va) * 3);

@@ -849,12 +849,19 @@ __global__ void pvk_loss_final(const float* __restrict__ recon, const float* __r
 // Wide encoder backward + Adam: dW1[l][u] = 0.5 * sum_b code(b,l) * dpre1[b][u]; M = l, N = u, K = b.
 // One wave per subtile; dpre1 staged once per workgroup in LDS.
 // ---------------------------------------------------------------------------------------------
-template <int NWB, int MODE>
-__global__ __launch_bounds__(256) void pvk_enc_bwd(const float* __restrict__ W1, const float* __restrict__ mW,
+// FUSE = 1 (ngrp == 1 only): the freshly updated tile, still in registers, is also multiplied with the NEXT
+// batch's genotype codes -- the next step's first-layer forward (pvk_enc_fwd) rides along, which saves one
+// full read of W1 (4 of the 52 bytes per wide parameter and step).  Partials go to fpart[workgroup][32][Wp]
+// exactly as pvk_enc_fwd writes them.
+template <int NWB, int MODE, int FUSE>
+__global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ W1, const float* __restrict__ mW,
                                                    const float* __restrict__ vW, float* __restrict__ W1o,
                                                    float* __restrict__ mWo, float* __restrict__ vWo,
                                                    const float* __restrict__ dpre, int ldp, const uint64_t* __restrict__ Xt,
-                                                   int nblk, int ngrp, const PvStep* st, PvAdam adam) {
+                                                   int nblk, int ngrp, const PvStep* st, PvAdam adam,
+                                                   const uint8_t* __restrict__ geno, int64_t row_bytes,
+                                                   const int* __restrict__ rows, int next_off, int next_n,
+                                                   float* __restrict__ fpart) {
     constexpr int WG_UNITS = NWB * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [ngrp][32][WG_UNITS]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
@@ -869,8 +876,24 @@ __global__ __launch_bounds__(256) void pvk_enc_bwd(const float* __restrict__ W1,
     const int64_t per = (ntasks + nwaves - 1) / nwaves;
     int64_t t0 = gw * per, t1 = t0 + per;
     if (t1 > ntasks) t1 = ntasks;
+    const uint8_t* nrow = nullptr;  // FUSE: lane c's sample of the next batch
+    f32x16 facc[NWB];
+    if (FUSE) {
+        if (c < next_n) nrow = geno + (int64_t)rows[next_off + c] * row_bytes;
+#pragma unroll
+        for (int w = 0; w < NWB; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) facc[w][r] = 0.f;
+    }
     for (int64_t t = t0; t < t1; ++t) {
         const int blk = (int)(t / ngrp), grp = (int)(t % ngrp);
+        uint32_t nlo = 0, nhi = 0;
+        if (FUSE) {
+            uint64_t xn = nrow ? *reinterpret_cast<const uint64_t*>(nrow + (int64_t)blk * 8) : 0ull;
+            xn >>= (8 * h);
+            nlo = (uint32_t)xn;
+            nhi = (uint32_t)(xn >> 32);
+        }
         const float* dp = smem + grp * 32 * WG_UNITS;
         uint64_t xw = Xt[blk * 32 + c] >> (8 * h);
         const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
@@ -913,8 +936,29 @@ __global__ __launch_bounds__(256) void pvk_enc_bwd(const float* __restrict__ W1,
                     __builtin_nontemporal_store(wq, oW + off);
                     __builtin_nontemporal_store(mq, oM + off);
                     __builtin_nontemporal_store(vq, oV + off);
+                    if (FUSE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            facc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv_code(nlo, nhi, q * 4 + e), wq[e], facc[w], 0, 0, 0);
+                    }
                 }
             }
+        }
+    }
+    if (FUSE) {
+        // fixed-order reduce of the 4 waves' forward fragments (same as pvk_enc_fwd's epilogue)
+        __syncthreads();  // dpre staging is dead
+        float* red = smem;  // [4][NWB*16][64]
+#pragma unroll
+        for (int w = 0; w < NWB; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave * NWB + w) * 16 + r) * 64 + lane] = facc[w][r];
+        __syncthreads();
+        float* p = fpart + (int64_t)blockIdx.x * (NWB * 1024);
+        for (int e = tid; e < NWB * 1024; e += 256) {
+            const float sum = ((red[e] + red[NWB * 1024 + e]) + red[2 * NWB * 1024 + e]) + red[3 * NWB * 1024 + e];
+            const int w = e >> 10, r = (e >> 6) & 15, ln = e & 63;
+            p[PV_ROW(r, ln >> 5) * (NWB * 32) + w * 32 + (ln & 31)] = sum;
         }
     }
 }

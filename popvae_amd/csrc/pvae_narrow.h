@@ -49,6 +49,18 @@ __device__ __forceinline__ void pvn_stage_ops(const T* __restrict__ ops, int nop
     const int n = nops * (int)(sizeof(T) / 4);
     for (int e = tid; e < n; e += PVN_THREADS) ops_s[e] = reinterpret_cast<const int*>(ops)[e];
 }
+// L2 warm-up role.  The narrow kernels are launched with 8 * (nops + 1) workgroups; workgroup 0 does the work.
+// Workgroups 8, 16, 24, ... are (by the dispatcher's round-robin placement) on the same XCD as workgroup 0 and
+// share its L2: workgroup 8*(p+1) pulls op p's weight matrix through that L2 and exits, so that the worker's
+// operand loads -- 64 KB per layer, cold after the gigabytes the wide kernels streamed -- hit L2 instead of
+// paying several HBM round trips per layer.  Purely a hint: placement affects speed only, never results.
+__device__ __forceinline__ void pvn_warm_l2(const float* p, int nfloats, int tid) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* q = reinterpret_cast<const f32x4*>(p);
+    for (int e = tid; e < (nfloats >> 2); e += PVN_THREADS) acc += q[e];
+    asm volatile("" ::"v"(acc));
+}
+
 template <typename T>
 __device__ __forceinline__ T pvn_get_op(const int* ops_s, int i) {
     constexpr int ND = sizeof(T) / 4;
@@ -98,10 +110,13 @@ struct PvW32 {
 // ---------------------------------------------------------------------------------------------
 template <int NB>
 __device__ __forceinline__ PvW32 pvn_fwd_load(PvW32 w, const float* W, int N, int k0, int steps, int c, int h) {
+    // NOTE: no per-load guards.  A load under a (even wave-uniform) runtime condition makes hipcc branch around it
+    // and wait vmcnt(0) per element -- 8 serial memory round trips; steps beyond `steps` re-load the last row.
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-        if (s < steps) {
-            const float* src = W + (k0 + 2 * s + h) * N + NB * c;
+    for (int s = 0; s < 8; ++s) {
+        {
+            const int sc = s < steps ? s : steps - 1;
+            const float* src = W + (k0 + 2 * sc + h) * N + NB * c;
             if (NB == 4) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(src);
 #pragma unroll
@@ -115,6 +130,7 @@ __device__ __forceinline__ PvW32 pvn_fwd_load(PvW32 w, const float* W, int N, in
                 for (int t = 0; t < NB; ++t) PVN_WSET(w, s * 4 + t, src[t]);
             }
         }
+    }
     return w;
 }
 
@@ -173,6 +189,14 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
     int* ops_s = reinterpret_cast<int*>(bias_s + 128);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int row0 = tid >> 5, col0 = tid & 31;
+    if (blockIdx.x != 0) {
+        const int p = (int)(blockIdx.x >> 3) - 1;
+        if ((blockIdx.x & 7) == 0 && p < nops) {
+            const PvFwdOp op = ops[p];
+            if (op.kind == PVN_DENSE) pvn_warm_l2(op.W, op.kin * op.nout, tid);
+        }
+        return;
+    }
     pvn_stage_ops(ops, nops, ops_s, tid);
     __syncthreads();
 
@@ -183,7 +207,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
     auto prefetch = [&](int i) {
         if (i >= nops) return;
         const PvFwdOp op = pvn_get_op<PvFwdOp>(ops_s, i);
-        if (op.b && tid < op.nout) bnext = op.b[tid];
+        bnext = op.b[tid < op.nout ? tid : op.nout - 1];  // op.b is never null (REPARAM carries a dummy)
         if (op.kind != PVN_DENSE) return;
         const int kw = op.kin >> 3, steps = kw >> 1, k0 = wave * kw;
         switch (op.nout >> 5) {
@@ -198,6 +222,10 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
         const PvFwdOp op = pvn_get_op<PvFwdOp>(ops_s, i);
         PVN_T(i * 8 + 0);
         const PvW32 wcur = wnext;
+#ifdef PVN_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PVN_T(i * 8 + 1);
+#endif
         if (tid < 128) bias_s[tid] = bnext;  // read after this op's first barrier at the earliest
         prefetch(i + 1);
         PVN_T(i * 8 + 5);
@@ -208,7 +236,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
             for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    pv[rr][j] = j * 32 < N ? P[(row0 + 16 * rr) * N + j * 32 + col0] : 0.f;
+                    pv[rr][j] = P[(row0 + 16 * rr) * N + (j * 32 < N ? j : 0) * 32 + col0];  // clamped, never guarded
             __syncthreads();
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr)
@@ -248,6 +276,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
                 kl_out[b] = -0.5f * acc;
             }
         } else {
+            PVN_T(i * 8 + 2);
             switch (N >> 5) {
                 case 1: pvn_fwd_dense<1>(op, wcur, act, red, bias_s, tid); break;
                 case 2: pvn_fwd_dense<2>(op, wcur, act, red, bias_s, tid); break;
@@ -310,6 +339,15 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     int* ops_s = reinterpret_cast<int*>(red + 8 * 1024);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int row0 = tid >> 5, col0 = tid & 31;
+    if (blockIdx.x != 0) {
+        const int p = (int)(blockIdx.x >> 3) - 1;
+        if (update && (blockIdx.x & 7) == 0 && p < nops) {
+            const PvBwdOp op = ops[p];
+            if (op.kind == PVN_DENSE) pvn_warm_l2(op.W, op.kin * op.nout, tid);
+            if (op.kind != PVN_REPARAM && op.act == PV_ACT_ELU) pvn_warm_l2(op.Y, 32 * op.nout, tid);
+        }
+        return;
+    }
     if (update) pvn_stage_ops(ops, nops, ops_s, tid);
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
@@ -341,7 +379,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
             for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (j * 32 < N) ynext[rr][j] = op.Y[(row0 + 16 * rr) * N + j * 32 + col0];
+                    ynext[rr][j] = op.Y[(row0 + 16 * rr) * N + (j * 32 < N ? j : 0) * 32 + col0];  // clamped
         }
         if (op.kind != PVN_DENSE || kb * 32 >= op.kin) return;
         const int chunk = N >> 1, half = chunk >> 1;
@@ -349,14 +387,18 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
         PVN_SWITCH(half, wnext = pvn_load_contig<S_>(wnext, src));
     };
     prefetch(0);
+    {
+        float xv[2][4];
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr)
+        for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j * 32 < W0) {
-                const int b = row0 + 16 * rr, n = j * 32 + col0;
-                dY_s[b * PVN_LD + n] = xch[b * W0 + n];
-            }
+            for (int j = 0; j < 4; ++j) xv[rr][j] = xch[(row0 + 16 * rr) * W0 + (j * 32 < W0 ? j : 0) * 32 + col0];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j * 32 < W0) dY_s[(row0 + 16 * rr) * PVN_LD + j * 32 + col0] = xv[rr][j];
+    }
     __syncthreads();
 
     for (int i = 0; i < nops; ++i) {

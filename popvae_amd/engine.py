@@ -53,7 +53,7 @@ def lib():
         L.pvae_last_error.argtypes = [vp]
         L.pvae_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
         L.pvae_destroy.argtypes = [vp]
-        L.pvae_set_stream.argtypes = [vp, vp]
+        L.pvae_set_stream.argtypes = [vp, vp, C.c_int]
         L.pvae_synchronize.argtypes = [vp]
         L.pvae_load_genotypes.argtypes = [vp, _u8p, i64, i64]
         L.pvae_num_tensors.argtypes = [vp]
@@ -131,8 +131,10 @@ class Engine:
         except Exception:
             pass
 
-    def set_stream(self, stream_ptr):
-        self._ck(lib().pvae_set_stream(self._h, C.c_void_p(stream_ptr)))
+    def set_stream(self, stream_ptr, own=False):
+        """Run the engine on ``stream_ptr`` (a hipStream_t; 0 / None = the legacy default stream), or on its own
+        stream again with ``own=True``."""
+        self._ck(lib().pvae_set_stream(self._h, C.c_void_p(stream_ptr or 0), int(bool(own))))
 
     def synchronize(self):
         self._ck(lib().pvae_synchronize(self._h))

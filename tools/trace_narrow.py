@@ -16,4 +16,6 @@ for i in range(14):
     r=a[i*8:(i+1)*8]
     nxt=a[(i+1)*8]
     w=[(x[0]-r[0][0])*10 for x in r]
-    print(i, "prefetch_issued %5d | op_total %5d ns"%(w[5], (nxt[0]-r[0][0])*10))
+    print(i, "waited_w %5d | prefetch_issued %5d | dense_start %5d | op_total %5d ns"%(w[1], w[5], w[2], (nxt[0]-r[0][0])*10))
+r=a[60*8:61*8]
+print("last dense op: mma_done->after_barrier %d ns; after barrier to op end:"%((r[4][0]-r[3][0])*10), (a[14*8][0]-r[4][0])*10 if a[14*8][0] else None, " mma_done rel last op start", (r[3][0]-a[13*8][0])*10)
