@@ -33,6 +33,9 @@ struct Buf3 {  // weight + Adam slots (+ lazily allocated gradient dump / best s
     // wide tensors only: the "other" copy.  A train step streams w/m/v -> w2/m2/v2 and swaps: in-place
     // read-modify-write tops out ~15% below what separate read and write streams reach on HBM3E.
     float *w2 = nullptr, *m2 = nullptr, *v2 = nullptr;
+    // wide tensors: w | m | v live tile-interleaved in ONE allocation ([W 16K | m 16K | v 16K] per subtile), so that
+    // a step reads one contiguous window and writes one; m and v are then views (w + ts, w + 2 ts), ts = tile floats
+    int64_t il_tile = 0;  // 0 = plain separate arrays
     int64_t n = 0;
     void swap() { std::swap(w, w2); std::swap(m, m2); std::swap(v, v2); }
 };
@@ -82,6 +85,8 @@ struct pvae_engine {
     // scratch
     float *encpart = nullptr, *dgpart = nullptr, *losspart = nullptr;
     int enc_wgs = 0, dec_wgs = 0, encb_wgs = 0;
+    int64_t tile_floats = 0;
+    int ts4 = 0;
     // fused narrow stack (width <= 128): op tables in device memory
     bool fused_narrow = false, narrow_warm = true, fuse_fwd = false;
     PvFwdOp* d_fwd_ops = nullptr;
@@ -145,16 +150,40 @@ int alloc3(pvae_engine* e, Buf3& b, int64_t n) {
     HIPCHK(hipMemsetAsync(b.v, 0, n * sizeof(float), e->stream));
     return 0;
 }
-int alloc_pingpong(pvae_engine* e, Buf3& b) {
-    HIPCHK(hipMalloc(&b.w2, b.n * sizeof(float)));
-    HIPCHK(hipMalloc(&b.m2, b.n * sizeof(float)));
-    HIPCHK(hipMalloc(&b.v2, b.n * sizeof(float)));
+// wide tensor: two tile-interleaved copies (ping-pong pair), tile = floats per subtile
+int alloc_wide(pvae_engine* e, Buf3& b, int64_t n, int64_t tile) {
+    b.n = n;
+    b.il_tile = tile;
+    HIPCHK(hipMalloc(&b.w, 3 * n * sizeof(float)));
+    HIPCHK(hipMalloc(&b.w2, 3 * n * sizeof(float)));
+    HIPCHK(hipMemsetAsync(b.w, 0, 3 * n * sizeof(float), e->stream));
+    HIPCHK(hipMemsetAsync(b.w2, 0, 3 * n * sizeof(float), e->stream));
+    b.m = b.w + tile; b.v = b.w + 2 * tile;
+    b.m2 = b.w2 + tile; b.v2 = b.w2 + 2 * tile;
     return 0;
 }
 void free3(Buf3& b) {
-    hipFree(b.w); hipFree(b.m); hipFree(b.v); hipFree(b.g); hipFree(b.best);
-    hipFree(b.w2); hipFree(b.m2); hipFree(b.v2);
+    hipFree(b.w); hipFree(b.g); hipFree(b.best); hipFree(b.w2);
+    if (!b.il_tile) { hipFree(b.m); hipFree(b.v); hipFree(b.m2); hipFree(b.v2); }
     b = Buf3();
+}
+// copies between a (possibly tile-interleaved) parameter array and a plain one
+hipError_t copy_params(pvae_engine* e, Buf3& b, float* plain, bool to_plain) {
+    if (!b.il_tile) {
+        return to_plain ? hipMemcpyAsync(plain, b.w, b.n * 4, hipMemcpyDeviceToDevice, e->stream)
+                        : hipMemcpyAsync(b.w, plain, b.n * 4, hipMemcpyDeviceToDevice, e->stream);
+    }
+    const size_t tb = (size_t)b.il_tile * 4, rows = (size_t)(b.n / b.il_tile);
+    return to_plain ? hipMemcpy2DAsync(plain, tb, b.w, 3 * tb, tb, rows, hipMemcpyDeviceToDevice, e->stream)
+                    : hipMemcpy2DAsync(b.w, 3 * tb, plain, tb, tb, rows, hipMemcpyDeviceToDevice, e->stream);
+}
+hipError_t zero_moments(pvae_engine* e, Buf3& b) {
+    if (!b.il_tile) {
+        hipError_t s1 = hipMemsetAsync(b.m, 0, b.n * 4, e->stream);
+        return s1 != hipSuccess ? s1 : hipMemsetAsync(b.v, 0, b.n * 4, e->stream);
+    }
+    const size_t tb = (size_t)b.il_tile * 4;
+    return hipMemset2DAsync(b.m, 3 * tb, 0, 2 * tb, (size_t)(b.n / b.il_tile), e->stream);
 }
 int allocf(pvae_engine* e, float** p, int64_t n) {
     HIPCHK(hipMalloc(p, n * sizeof(float)));
@@ -316,7 +345,7 @@ int stage_a(pvae_engine* e, int row_offset, bool need_xt, bool fwd_done = false)
     } else {
         Timer t(e, C_ENC_FWD);
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_enc_fwd<N_>, dim3(e->enc_wgs), dim3(256), lds_enc_fwd(N_), e->stream, e->W1.w, e->geno,
-                                              e->row_bytes, e->d_rows, e->st, row_offset, e->nblk, e->ngrp, e->encpart));
+                                              e->row_bytes, e->d_rows, e->st, row_offset, e->nblk, e->ngrp, e->encpart, e->ts4));
         if ((rc = launch_check(e, "enc_fwd"))) return rc;
         hipLaunchKernelGGL(pvk_reduce_parts, dim3(32 * e->Wp / 64), dim3(256), 0, e->stream, e->encpart, e->enc_wgs / e->ngrp, 32 * e->Wp,
                            0.5f, e->P, (const float*)nullptr, (float*)nullptr);
@@ -432,7 +461,7 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
         if (e->ngrp > 1) {
 #define PV_DEC_G(G, TR, MD, V_, M_, VV_, V2_, M2_, VV2_, C_, MC_, VC_)                                                    \
     hipLaunchKernelGGL((pvk_dec_grp<G, TR, MD>), dim3(e->dec_wgs), dim3(512), lds_dec_grp(G), e->stream, V_, M_, VV_, V2_, M2_, \
-                       VV2_, C_, MC_, VC_, gD, e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart, e->losspart)
+                       VV2_, C_, MC_, VC_, gD, e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4)
 #define PV_DEC_GG(TR, MD, ...)                                  \
     do {                                                        \
         if (e->ngrp == 2) PV_DEC_G(2, TR, MD, __VA_ARGS__);     \
@@ -455,19 +484,19 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
             PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 1, PV_MODE_TRAIN>), dim3(e->dec_wgs), dim3(256), lds_dec(N_),
                                                   e->stream, e->Vout.w, e->Vout.m, e->Vout.v, e->Vout.w2, e->Vout.m2,
                                                   e->Vout.v2, e->cout.w, e->cout.m, e->cout.v, gD, e->Xt, e->nblk,
-                                                  (int)e->L, e->st, e->adam, e->dgpart, e->losspart));
+                                                  (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4));
             e->Vout.swap();
         } else if (mode == 2) {
             PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 1, PV_MODE_GRAD>), dim3(e->dec_wgs), dim3(256), lds_dec(N_),
                                                   e->stream, e->Vout.w, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                                                   e->Vout.g, (float*)nullptr, e->cout.w, e->cout.g, (float*)nullptr, gD,
-                                                  e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart, e->losspart));
+                                                  e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4));
         } else {
             PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 0, PV_MODE_TRAIN>), dim3(e->dec_wgs), dim3(256), lds_dec(N_),
                                                   e->stream, e->Vout.w, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                                                   (float*)nullptr, (float*)nullptr, e->cout.w, (float*)nullptr,
                                                   (float*)nullptr, gD, e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart,
-                                                  e->losspart));
+                                                  e->losspart, e->ts4));
         }
         if ((rc = launch_check(e, "dec"))) return rc;
         const int n_dg = mode == 1 ? 0 : 32 * e->Wp;
@@ -490,19 +519,19 @@ int enc_bwd_launch(pvae_engine* e, int km, bool fuse = false, int next_off = 0, 
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_GRAD, 0>), dim3(e->encb_wgs), dim3(256),
                                               lds_enc_bwd(e->Wp), e->stream, e->W1.w, (float*)nullptr, (float*)nullptr,
                                               (float*)nullptr, e->W1.g, (float*)nullptr, e->dpre1, e->Wp, e->Xt, e->nblk,
-                                              e->ngrp, e->st, e->adam, nog, (int64_t)0, nor, 0, 0, nof));
+                                              e->ngrp, e->st, e->adam, nog, (int64_t)0, nor, 0, 0, nof, e->ts4));
     } else if (fuse) {
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 1>), dim3(e->encb_wgs), dim3(256),
                                               lds_enc_bwd_fused(N_), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
                                               e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam,
                                               (const uint8_t*)e->geno, e->row_bytes, (const int*)e->d_rows, next_off, next_n,
-                                              e->encpart));
+                                              e->encpart, e->ts4));
         e->W1.swap();
     } else {
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 0>), dim3(e->encb_wgs), dim3(256),
                                               lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
                                               e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam, nog,
-                                              (int64_t)0, nor, 0, 0, nof));
+                                              (int64_t)0, nor, 0, 0, nof, e->ts4));
         e->W1.swap();
     }
     return launch_check(e, "enc_bwd");
@@ -694,7 +723,8 @@ int tensor_io(pvae_engine* e, int index, int which, float* host, int64_t count, 
             if (to_device) HIPCHK(hipMemcpy(tmp, host, (size_t)expect * 4, hipMemcpyHostToDevice));
             const int64_t total = b.n;
             hipLaunchKernelGGL(pvk_convert_wide, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, pick(b, which),
-                               tmp, t.kind == T_W1 ? 0 : 1, to_device ? 0 : 1, e->L, e->W, e->nblk, e->ngrp, e->NWB);
+                               tmp, t.kind == T_W1 ? 0 : 1, to_device ? 0 : 1, e->L, e->W, e->nblk, e->ngrp, e->NWB,
+                               (int)(which == 3 ? e->tile_floats : 3 * e->tile_floats));
             if ((rc = launch_check(e, "convert_wide"))) { hipFree(tmp); return rc; }
             HIPCHK(hipStreamSynchronize(e->stream));
             if (!to_device) HIPCHK(hipMemcpy(host, tmp, (size_t)expect * 4, hipMemcpyDeviceToHost));
@@ -790,10 +820,10 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     e->lr_host = cfg->lr;
 
     const int64_t wide_n = (int64_t)e->nblk * e->ngrp * e->NWB * 1024;
-    CK(alloc3(e, e->W1, wide_n));
-    CK(alloc3(e, e->Vout, wide_n));
-    CK(alloc_pingpong(e, e->W1));
-    CK(alloc_pingpong(e, e->Vout));
+    e->tile_floats = (int64_t)e->NWB * 1024;
+    e->ts4 = (int)(3 * e->NWB * 256);  // tile stride of the interleaved buffers in float4 units
+    CK(alloc_wide(e, e->W1, wide_n, e->tile_floats));
+    CK(alloc_wide(e, e->Vout, wide_n, e->tile_floats));
     CK(alloc3(e, e->cout, e->Lp));
     CK(alloc3(e, e->b1, e->Wp));
     e->enc.resize(e->D - 1);
@@ -978,7 +1008,7 @@ int pvae_reset_optimizer(pvae_engine* e) {
     HIPCHK(hipStreamSynchronize(e->stream));
     int rc = 0;
     for_each_buf(e, [&](Buf3& b) {
-        if (hipMemsetAsync(b.m, 0, b.n * 4, e->stream) != hipSuccess || hipMemsetAsync(b.v, 0, b.n * 4, e->stream) != hipSuccess) rc = -10;
+        if (zero_moments(e, b) != hipSuccess) rc = -10;
     });
     if (rc) return set_err(e, rc, "hipMemset failed");
     PvStep st0{};
@@ -1136,7 +1166,7 @@ int pvae_snapshot_best(pvae_engine* e) {
     for_each_buf(e, [&](Buf3& b) {
         if (rc) return;
         if (!b.best && hipMalloc(&b.best, b.n * 4) != hipSuccess) { rc = -10; return; }
-        if (hipMemcpyAsync(b.best, b.w, b.n * 4, hipMemcpyDeviceToDevice, e->stream) != hipSuccess) rc = -10;
+        if (copy_params(e, b, b.best, true) != hipSuccess) rc = -10;
     });
     if (rc) return set_err(e, rc, "snapshot failed: %s", hipGetErrorString(hipGetLastError()));
     e->has_best = true;
@@ -1147,7 +1177,7 @@ int pvae_restore_best(pvae_engine* e) {
     if (!e->has_best) return set_err(e, -6, "no snapshot taken");
     int rc = 0;
     for_each_buf(e, [&](Buf3& b) {
-        if (hipMemcpyAsync(b.w, b.best, b.n * 4, hipMemcpyDeviceToDevice, e->stream) != hipSuccess) rc = -10;
+        if (copy_params(e, b, b.best, false) != hipSuccess) rc = -10;
     });
     if (rc) return set_err(e, rc, "restore failed");
     HIPCHK(hipStreamSynchronize(e->stream));

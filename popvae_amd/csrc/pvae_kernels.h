@@ -129,7 +129,7 @@ template <int NWB>
 __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1, const uint8_t* __restrict__ geno,
                                                    int64_t row_bytes, const int* __restrict__ rows,
                                                    const PvStep* st, int row_offset, int nblk, int ngrp,
-                                                   float* __restrict__ part) {
+                                                   float* __restrict__ part, int ts) {
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     // all 4 waves of a workgroup work on the same group of 128 units (their fragments are summed below);
     // gridDim.x is a multiple of ngrp
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1,
         for (int r = 0; r < 16; ++r) acc[w][r] = 0.f;
 
     for (int blk = slot; blk < nblk; blk += nslots) {  // round-robin, see pvk_dec
-        const f32x4* tile = reinterpret_cast<const f32x4*>(W1) + ((int64_t)blk * ngrp + grp) * (NWB * 256);
+        const f32x4* tile = reinterpret_cast<const f32x4*>(W1) + ((int64_t)blk * ngrp + grp) * ts;
         f32x4 wv[NWB][4];
 #pragma unroll
         for (int w = 0; w < NWB; ++w)
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
                                                   float* __restrict__ cb, float* __restrict__ mC, float* __restrict__ vC,
                                                   const float* __restrict__ g, const uint64_t* __restrict__ Xt,
                                                   int nblk, int L, const PvStep* st, PvAdam adam,
-                                                  float* __restrict__ dgpart, float* __restrict__ losspart) {
+                                                  float* __restrict__ dgpart, float* __restrict__ losspart, int ts) {
     constexpr int WP = NWB * 32;
     constexpr int LDG = WP + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -467,7 +467,10 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
     for (int blk = gw; blk < nblk; blk += nwaves) {
         // keep the (loop-invariant) g operand reads inside the loop: hoisting them costs 128 VGPRs
         asm volatile("" ::: "memory");
-        const int64_t tbase = (int64_t)blk * (NWB * 256);  // in f32x4 units
+        // ts = tile stride in f32x4 units: the W / m / v tiles of a subtile are interleaved in one buffer
+        // ([W 16K | m 16K | v 16K] per subtile, ts = 3 * NWB * 256), so a step reads ONE window and writes ONE
+        const int64_t tbase = (int64_t)blk * ts;
+        const int64_t gbase = (int64_t)blk * (NWB * 256);  // gradient dumps (MODE_GRAD) are plain tiles
         const f32x4* tV = reinterpret_cast<const f32x4*>(V) + tbase;
         f32x4 vv[NWB][4];
 #pragma unroll
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
             const f32x4* tM = reinterpret_cast<const f32x4*>(mV) + tbase;
             const f32x4* tVv = reinterpret_cast<const f32x4*>(vV) + tbase;
             f32x4* dV2 = reinterpret_cast<f32x4*>(V2) + tbase;
-            f32x4* dM2 = reinterpret_cast<f32x4*>(mV2) + tbase;
+            f32x4* dM2 = reinterpret_cast<f32x4*>(mV2) + (MODE == PV_MODE_GRAD ? gbase : tbase);
             f32x4* dVv2 = reinterpret_cast<f32x4*>(vV2) + tbase;
 #pragma unroll
             for (int w = 0; w < NWB; ++w) {
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
                                                    float* __restrict__ cb, float* __restrict__ mC, float* __restrict__ vC,
                                                    const float* __restrict__ g, const uint64_t* __restrict__ Xt,
                                                    int nblk, int L, const PvStep* st, PvAdam adam,
-                                                   float* __restrict__ dgpart, float* __restrict__ losspart) {
+                                                   float* __restrict__ dgpart, float* __restrict__ losspart, int ts) {
     constexpr int NWB = 4;
     constexpr int WP = NGRP * 128;
     constexpr int LDG = WP + 1;
@@ -661,7 +664,8 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
         const int bg = it * (int)gridDim.x + blockIdx.x;  // round-robin over workgroups
         const int blk = bg * BPI + bsub;
         const bool valid = bg < bgroups && blk < nblk;  // wave-uniform; invalid waves only keep the barriers
-        const int64_t tbase = ((int64_t)blk * NGRP + grp) * (NWB * 256);  // in f32x4 units
+        const int64_t tbase = ((int64_t)blk * NGRP + grp) * ts;            // interleaved W|m|v tiles
+        const int64_t gbase = ((int64_t)blk * NGRP + grp) * (NWB * 256);  // plain tiles (gradient dump)
         const f32x4* tV = reinterpret_cast<const f32x4*>(V) + tbase;
         f32x4 vv[NWB][4];
         f32x16 a;
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
             const f32x4* tM = reinterpret_cast<const f32x4*>(mV) + tbase;
             const f32x4* tVv = reinterpret_cast<const f32x4*>(vV) + tbase;
             f32x4* dV2 = reinterpret_cast<f32x4*>(V2) + tbase;
-            f32x4* dM2 = reinterpret_cast<f32x4*>(mV2) + tbase;
+            f32x4* dM2 = reinterpret_cast<f32x4*>(mV2) + (MODE == PV_MODE_GRAD ? gbase : tbase);
             f32x4* dVv2 = reinterpret_cast<f32x4*>(vV2) + tbase;
 #pragma unroll
             for (int w = 0; w < NWB; ++w) {
@@ -855,7 +859,7 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
                                                    int nblk, int ngrp, const PvStep* st, PvAdam adam,
                                                    const uint8_t* __restrict__ geno, int64_t row_bytes,
                                                    const int* __restrict__ rows, int next_off, int next_n,
-                                                   float* __restrict__ fpart) {
+                                                   float* __restrict__ fpart, int ts) {
     constexpr int WG_UNITS = NWB * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [ngrp][32][WG_UNITS]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
@@ -891,12 +895,12 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
         float xa[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) xa[r] = pv_code(lo, hi, r);
-        const f32x4* tW = reinterpret_cast<const f32x4*>(W1) + t * (NWB * 256);
-        const f32x4* tM = reinterpret_cast<const f32x4*>(mW) + t * (NWB * 256);
-        const f32x4* tV = reinterpret_cast<const f32x4*>(vW) + t * (NWB * 256);
-        f32x4* oW = reinterpret_cast<f32x4*>(W1o) + t * (NWB * 256);
-        f32x4* oM = reinterpret_cast<f32x4*>(mWo) + t * (NWB * 256);
-        f32x4* oV = reinterpret_cast<f32x4*>(vWo) + t * (NWB * 256);
+        const f32x4* tW = reinterpret_cast<const f32x4*>(W1) + t * ts;  // interleaved W|m|v tiles, see pvk_dec
+        const f32x4* tM = reinterpret_cast<const f32x4*>(mW) + t * ts;
+        const f32x4* tV = reinterpret_cast<const f32x4*>(vW) + t * ts;
+        f32x4* oW = reinterpret_cast<f32x4*>(W1o) + t * ts;
+        f32x4* oM = reinterpret_cast<f32x4*>(mWo) + t * (MODE == PV_MODE_GRAD ? (int64_t)(NWB * 256) : (int64_t)ts);
+        f32x4* oV = reinterpret_cast<f32x4*>(vWo) + t * ts;
 #pragma unroll
         for (int w = 0; w < NWB; ++w) {
             f32x16 dw;
@@ -991,7 +995,7 @@ __global__ void pvk_gen_eps(float* __restrict__ eps, int n, uint64_t seed, uint6
 // One thread per tiled element (padding elements are written as zero on import).
 // ---------------------------------------------------------------------------------------------
 __global__ void pvk_convert_wide(float* __restrict__ tiled, float* __restrict__ keras, int kind, int dir, int64_t L,
-                                 int W, int nblk, int ngrp, int NWB) {
+                                 int W, int nblk, int ngrp, int NWB, int tile_stride /* floats between subtiles */) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)nblk * ngrp * NWB * 1024;
     if (i >= total) return;
@@ -1012,8 +1016,9 @@ __global__ void pvk_convert_wide(float* __restrict__ tiled, float* __restrict__ 
     }
     const bool inside = l < L && u < W;
     const int64_t kidx = kind == 0 ? l * W + u : (int64_t)u * L + l;
+    const int64_t ti = (i / (NWB * 1024)) * tile_stride + (i % (NWB * 1024));
     if (dir == 0)
-        tiled[i] = inside ? keras[kidx] : 0.f;
+        tiled[ti] = inside ? keras[kidx] : 0.f;
     else if (inside)
-        keras[kidx] = tiled[i];
+        keras[kidx] = tiled[ti];
 }

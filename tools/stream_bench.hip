@@ -76,6 +76,30 @@ __global__ __launch_bounds__(256) void k_chunk_oop(const f32x4* a, const f32x4* 
     }
 }
 
+// B3: like B2 (round-robin) but the three arrays are interleaved chunk-wise in ONE buffer: [x chunk | y chunk | z chunk]...
+template <int UNR>
+__global__ __launch_bounds__(256) void k_chunk_oop_il(const f32x4* a, f32x4* a2, size_t nchunks) {
+    const int lane = threadIdx.x & 63;
+    const size_t gw = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (size_t)gridDim.x * 4;
+    for (size_t ch = gw; ch < nchunks; ch += nw) {
+        f32x4 x[UNR], y[UNR], z[UNR];
+        const size_t o = ch * 3 * UNR * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            x[u] = __builtin_nontemporal_load(a + o + u * 64);
+            y[u] = __builtin_nontemporal_load(a + o + (UNR + u) * 64);
+            z[u] = __builtin_nontemporal_load(a + o + (2 * UNR + u) * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            x[u] = x[u] * 1.0001f + y[u] * 0.001f; y[u] = y[u] * 0.9f + z[u]; z[u] = z[u] * 0.999f + x[u];
+            __builtin_nontemporal_store(x[u], a2 + o + u * 64);
+            __builtin_nontemporal_store(y[u], a2 + o + (UNR + u) * 64);
+            __builtin_nontemporal_store(z[u], a2 + o + (2 * UNR + u) * 64);
+        }
+    }
+}
+
 // C: out-of-place (ping-pong) variant of A, and a read-only reduction
 template <int NT>
 __global__ __launch_bounds__(256) void k_oop(const f32x4* a, const f32x4* b, const f32x4* c, f32x4* a2, f32x4* b2, f32x4* c2, size_t n4) {
@@ -132,6 +156,13 @@ int main() {
         vs.push_back({"inplace stride 3arr nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_stride<3, 1>), dim3(g), dim3(256), 0, 0, A, B, C, n4); }, 3, {}});
         vs.push_back({"oop stride 3arr g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_oop<0>), dim3(g), dim3(256), 0, 0, A, B, C, A2, B2, C2, n4); }, 3, {}});
         vs.push_back({"oop stride 3arr nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_oop<1>), dim3(g), dim3(256), 0, 0, A, B, C, A2, B2, C2, n4); }, 3, {}});
+    }
+    float *il, *il2;
+    hipMalloc(&il, 3 * n * 4); hipMalloc(&il2, 3 * n * 4); hipMemset(il, 0, 3 * n * 4); hipMemset(il2, 0, 3 * n * 4);
+    f32x4 *IL = (f32x4*)il, *IL2 = (f32x4*)il2;
+    for (int g : {512, 768, 1024}) {
+        vs.push_back({"oop interleaved chunk16 nt rr g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk_oop_il<16>), dim3(g), dim3(256), 0, 0, IL, IL2, n4 / (16 * 64)); }, 3, {}});
+        vs.push_back({"oop interleaved chunk4 nt rr g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk_oop_il<4>), dim3(g), dim3(256), 0, 0, IL, IL2, n4 / (4 * 64)); }, 3, {}});
     }
     for (int g : {512, 768, 1024}) {
         vs.push_back({"inplace chunk16 contiguous g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk<3, 16, 0>), dim3(g), dim3(256), 0, 0, A, B, C, n4 / (16 * 64)); }, 3, {}});
