@@ -82,6 +82,7 @@ struct pvae_engine {
     float* xch1 = nullptr;              // exchange buffer 1: [32*Wp] dg_D + [32] recon
     float *dA = nullptr, *dB = nullptr, *dpre1 = nullptr, *dheads = nullptr, *dz = nullptr;
     uint64_t* Xt = nullptr;
+    float* probs = nullptr;  // decoder.predict staging [32][L], allocated on first pvae_decode
     // scratch
     float *encpart = nullptr, *dgpart = nullptr, *losspart = nullptr;
     int enc_wgs = 0, dec_wgs = 0, encb_wgs = 0;
@@ -410,10 +411,10 @@ int build_fwd_ops(pvae_engine* e) {
     return 0;
 }
 
-int narrow_fused_fwd(pvae_engine* e, bool encoder_only) {
+int narrow_fused_fwd(pvae_engine* e, bool encoder_only, bool decoder_only = false) {
     const int nops = encoder_only ? e->n_enc_ops : e->n_fwd_ops;
     hipLaunchKernelGGL(pvk_narrow_fwd, dim3(e->narrow_warm ? 8 * (nops + 1) : 1), dim3(PVN_THREADS), pvn_lds_fwd(), e->stream,
-                       e->d_fwd_ops, nops, e->P, e->eps, e->K, e->Kz, e->z, e->kl);
+                       e->d_fwd_ops, decoder_only ? e->n_enc_ops : 0, nops, e->P, e->eps, e->K, e->Kz, e->z, e->kl);
     return launch_check(e, "narrow_fwd");
 }
 
@@ -947,6 +948,7 @@ int pvae_destroy(pvae_engine* e) {
     for (auto p : fl) hipFree(p);
     hipFree(e->d_fwd_ops); hipFree(e->d_bwd_ops); hipFree(e->d_bwd_ops_grad);
     for (auto p : e->dpre_bufs) hipFree(p);
+    hipFree(e->probs);
     hipFree(e->Xt); hipFree(e->geno); hipFree(e->st); hipFree(e->d_rows); hipFree(e->d_ntotal); hipFree(e->d_counter);
     for (auto& ev : e->evs) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     for (auto& sl : e->slots) { if (sl.host) hipHostFree(sl.host); if (sl.ev) hipEventDestroy(sl.ev); }
@@ -1157,8 +1159,34 @@ int pvae_encode(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
 }
 
 int pvae_decode(pvae_engine* e, const float* z, int32_t n, float* probs) {
-    (void)z; (void)n; (void)probs;
-    return set_err(e, -7, "pvae_decode: not built yet (SURVEY 8f row 3)");
+    int rc;
+    if (n < 0 || !z || !probs) return set_err(e, -2, "pvae_decode: bad arguments");
+    if (!e->probs) HIPCHK(hipMalloc(&e->probs, (size_t)32 * e->L * sizeof(float)));
+    std::vector<float> zp((size_t)32 * e->Kz);
+    for (int i0 = 0; i0 < n; i0 += 32) {
+        const int nb = std::min(32, n - i0);
+        std::fill(zp.begin(), zp.end(), 0.f);
+        for (int b = 0; b < nb; ++b)
+            for (int k = 0; k < e->K; ++k) zp[(size_t)b * e->Kz + k] = z[(size_t)(i0 + b) * e->K + k];
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpy(e->z, zp.data(), zp.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (e->fused_narrow) {
+            if ((rc = narrow_fused_fwd(e, false, true))) return rc;
+        } else if ((rc = narrow_decoder(e))) {
+            return rc;
+        }
+        const size_t lds = (size_t)32 * (e->Wp + 1) * 4;
+        PV_DISPATCH_NWB(e, {
+            HIPCHK(allow_lds(pvk_dec_probs<N_>, lds));
+            hipLaunchKernelGGL(pvk_dec_probs<N_>, dim3(std::min(e->nblk / 4 + 1, 1024)), dim3(256), lds, e->stream, e->Vout.w,
+                               e->cout.w, e->g[e->D - 1], e->nblk, e->L, e->ngrp, e->ts4, nb, e->probs);
+        });
+        if ((rc = launch_check(e, "dec_probs"))) return rc;
+        HIPCHK(hipMemcpyAsync(probs + (size_t)i0 * e->L, e->probs, (size_t)nb * e->L * sizeof(float), hipMemcpyDeviceToHost,
+                              e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return 0;
 }
 
 int pvae_snapshot_best(pvae_engine* e) {

@@ -830,6 +830,55 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// decoder.predict (scripts/popvae_decoder_tests_HGDP.py:156): probs[b][l] = sigmoid(g_D[b] . V[:, l] + c[l]) for
+// b < nrows.  One wave per SNP block, looping over the unit groups; read-only pass over V (HBM-bound,
+// 4 B per wide parameter + 4 B per output).
+// ---------------------------------------------------------------------------------------------
+template <int NWB>
+__global__ __launch_bounds__(256) void pvk_dec_probs(const float* __restrict__ V, const float* __restrict__ cb,
+                                                     const float* __restrict__ g, int nblk, int64_t L, int ngrp, int ts,
+                                                     int nrows, float* __restrict__ probs) {
+    const int WP = ngrp * NWB * 32, LDG = WP + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // g_s [32][LDG]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int gw = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    for (int i = tid; i < 32 * WP; i += 256) smem[(i / WP) * LDG + (i % WP)] = g[i];
+    __syncthreads();
+    for (int blk = gw; blk < nblk; blk += nwaves) {
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+        for (int grp = 0; grp < ngrp; ++grp) {
+            const f32x4* tV = reinterpret_cast<const f32x4*>(V) + ((int64_t)blk * ngrp + grp) * ts;
+            f32x4 vv[NWB][4];
+#pragma unroll
+            for (int w = 0; w < NWB; ++w)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vv[w][q] = __builtin_nontemporal_load(tV + (w * 4 + q) * 64 + lane);
+#pragma unroll
+            for (int w = 0; w < NWB; ++w)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ga = smem[c * LDG + (grp * NWB + w) * 32 + PV_ROW(r, h)];
+                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, vv[w][r >> 2][r & 3], a, 0, 0, 0);
+                }
+        }
+        const int64_t l = (int64_t)blk * 32 + c;
+        if (l < L) {
+            const float bias = cb[l];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = PV_ROW(r, h);
+                const float z = a[r] + bias;
+                const float e = __expf(-fabsf(z));
+                const float inv = __builtin_amdgcn_rcpf(1.f + e);
+                if (b < nrows) probs[(int64_t)b * L + l] = z >= 0.f ? inv : e * inv;
+            }
+        }
+    }
+}
+
 // loss = mean_b(recon + kl) over valid rows (popvae.py:423) -> out[0..2] = loss, mean recon, mean kl
 __global__ void pvk_loss_final(const float* __restrict__ recon, const float* __restrict__ kl, const PvStep* st,
                                float* __restrict__ out) {

@@ -178,7 +178,7 @@ __device__ __forceinline__ void pvn_fwd_dense(const PvFwdOp& op, const PvW32& w,
     }
 }
 
-__global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __restrict__ ops, int nops,
+__global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __restrict__ ops, int op0, int nops,
                                                               const float* __restrict__ P,
                                                               const float* __restrict__ eps, int K, int Kz,
                                                               float* __restrict__ z_out, float* __restrict__ kl_out) {
@@ -217,8 +217,13 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
             default: wnext = pvn_fwd_load<4>(wnext, op.W, op.nout, k0, steps, c, h); break;
         }
     };
-    prefetch(0);
-    for (int i = 0; i < nops; ++i) {
+    if (op0 > 0) {  // decoder.predict: start behind REPARAM with z (already in z_out) as the activation
+        if (tid < 32)
+            for (int k = 0; k < Kz; ++k) act[tid * PVN_LD + k] = z_out[tid * Kz + k];
+        __syncthreads();
+    }
+    prefetch(op0);
+    for (int i = op0; i < nops; ++i) {
         const PvFwdOp op = pvn_get_op<PvFwdOp>(ops_s, i);
         PVN_T(i * 8 + 0);
         const PvW32 wcur = wnext;

@@ -231,6 +231,15 @@ class Engine:
         self._ck(lib().pvae_encode(self._h, rows, n, _fptr(eps), _fptr(mu), _fptr(lv), _fptr(z)))
         return mu, lv, z
 
+    def decode(self, z):
+        """decoder.predict (scripts/popvae_decoder_tests_HGDP.py:156): z [n, latent_dim] -> probabilities [n, n_snps]."""
+        z = np.ascontiguousarray(z, dtype=np.float32)
+        if z.ndim != 2 or z.shape[1] != self.latent_dim:
+            raise ValueError("z must be [n, latent_dim]")
+        out = np.empty((z.shape[0], self.n_snps), np.float32)
+        self._ck(lib().pvae_decode(self._h, z.reshape(-1), z.shape[0], out.reshape(-1)))
+        return out
+
     def snapshot_best(self):
         self._ck(lib().pvae_snapshot_best(self._h))
 

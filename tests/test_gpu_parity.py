@@ -125,6 +125,19 @@ def test_encode_matches_oracle():
     e.close()
 
 
+@pytest.mark.parametrize("L,W,D,K", [(500, 128, 4, 2), (333, 64, 2, 3), (700, 256, 3, 2), (40, 512, 2, 2)])
+def test_decode_matches_oracle(L, W, D, K):
+    dc, w = _problem(10, L, W, D, K, seed=9)
+    e = _mk(dc, w, W, D, K)
+    z = np.random.default_rng(1).normal(size=(45, K)).astype(np.float32)   # > 32 rows: two decode batches
+    p = e.decode(z)
+    w32 = [x.astype(np.float32).astype(np.float64) for x in w]
+    po = O.decode(w32, z.astype(np.float64), D, K)
+    assert p.shape == po.shape
+    assert np.abs(p - po).max() <= 2e-5
+    e.close()
+
+
 def test_epoch_matches_stepwise_and_learns():
     N, L, W, D, K = 95, 2000, 128, 3, 2
     g = np.random.default_rng(0)
