@@ -75,6 +75,29 @@ def test_loss_and_gradients(N, L, W, D, K, n):
     e.close()
 
 
+def test_golden_model_steps():
+    """HIP engine vs the committed golden fixture (tests/golden/model_steps.npz, logits BCE form)."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "model_steps.npz"))
+    L, W, D, K, N = (int(x) for x in G["dims"])
+    nt = 4 * D + 6
+    e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=32, seed=0)
+    e.load_genotypes(prep.pack_dc(G["codes"] * 0.5))
+    e.set_weights([G[f"w0_{i}"] for i in range(nt)])
+    loss, recon, kl = e.grad_step(G["rows_0"], G["eps_0"])
+    ref = G["logits_loss_0"]
+    assert abs(loss - ref[0]) <= RTOL * abs(ref[0]) and abs(recon - ref[1]) <= RTOL * abs(ref[1])
+    for i, a in enumerate(e.get_grads()):
+        assert _relerr(a, G[f"logits_grad0_{i}"]) <= RTOL, i
+    for s in range(3):
+        l, _, _ = e.train_step(G[f"rows_{s}"], G[f"eps_{s}"])
+        assert abs(l - G[f"logits_loss_{s}"][0]) <= RTOL * abs(G[f"logits_loss_{s}"][0]), s
+    for i, (a, m, v) in enumerate(zip(e.get_weights(), e.get_moments(0), e.get_moments(1))):
+        assert np.abs(a - G[f"logits_w3_{i}"]).max() <= 2e-2 * 3e-3, ("w", i)   # 2 % of the 3*lr travel
+        assert _relerr(m, G[f"logits_m3_{i}"]) <= 1e-3 and _relerr(v, G[f"logits_v3_{i}"]) <= 1e-3, ("mv", i)
+    e.close()
+
+
 def test_weight_roundtrip_and_layouts():
     dc, w = _problem(10, 333, 96, 3, 2, seed=5)
     e = _mk(dc, w, 96, 3, 2)

@@ -138,3 +138,27 @@ def test_fit_runs_and_improves():
                               prediction_freq=5)
     assert hist["loss"][-1] < hist["loss"][0]
     assert len(hist["lr"]) == 30 and [e for e, _ in preds] == [0, 5, 10, 15, 20, 25]
+
+
+def test_oracle_reproduces_committed_golden_steps():
+    """tests/golden/model_steps.npz (tests/make_golden_model.py): three Keras-Adam steps, both BCE forms."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "model_steps.npz"))
+    L, W, D, K, N = (int(x) for x in G["dims"])
+    nt = 4 * D + 6
+    dc = G["codes"] * 0.5
+    for mode in ("logits", "probs"):
+        w = [G[f"w0_{i}"].astype(np.float64) for i in range(nt)]
+        opt = O.KerasAdam(w)
+        for s in range(3):
+            c = O.forward(w, dc[G[f"rows_{s}"]], G[f"eps_{s}"].astype(np.float64), D, K, bce_mode=mode)
+            gr = O.backward(w, c, D, K, bce_mode=mode)
+            np.testing.assert_allclose([c["loss"], c["recon"].mean(), c["kl"].mean()], G[f"{mode}_loss_{s}"], rtol=1e-12)
+            if s == 0:
+                for i, t in enumerate(gr):
+                    np.testing.assert_allclose(t, G[f"{mode}_grad0_{i}"], rtol=1e-10, atol=1e-14)
+            opt.step(w, gr)
+        for i in range(nt):
+            np.testing.assert_allclose(w[i], G[f"{mode}_w3_{i}"], rtol=1e-10, atol=1e-14)
+    # the two BCE forms agree to O(1e-7) on the loss (SURVEY K5) -- which is why only the logits form is built in HIP
+    assert abs(G["logits_loss_0"][0] - G["probs_loss_0"][0]) <= 1e-5 * abs(G["logits_loss_0"][0])
