@@ -260,8 +260,7 @@ hipError_t allow_lds(Kern k, size_t bytes) {
 int setup_kernel_attrs(pvae_engine* e) {
     int maxK = std::max(e->Wp, std::max(e->Kh, e->Kz));
     HIPCHK(allow_lds(pvk_dense_fwd, lds_dense_fwd(maxK)));
-    HIPCHK(allow_lds(pvk_dense_bwd<PV_MODE_TRAIN>, lds_dense_bwd(maxK)));
-    HIPCHK(allow_lds(pvk_dense_bwd<PV_MODE_GRAD>, lds_dense_bwd(maxK)));
+    HIPCHK(allow_lds(pvk_dense_bwd, lds_dense_bwd(maxK)));
     HIPCHK(allow_lds(pvk_narrow_fwd, pvn_lds_fwd()));
     HIPCHK(allow_lds(pvk_narrow_bwd<PV_MODE_TRAIN>, pvn_lds_bwd()));
     HIPCHK(allow_lds(pvk_narrow_bwd<PV_MODE_GRAD>, pvn_lds_bwd()));
@@ -313,17 +312,9 @@ int run_dense_fwd(pvae_engine* e, const Dense& d, const float* in, float* out) {
     return launch_check(e, "dense_fwd");
 }
 
-int run_dense_bwd(pvae_engine* e, Dense& d, const float* in, const float* Y, const float* dY, float* dIn, int mode) {
-    if (mode == PV_MODE_GRAD) {
-        if (!d.W.g) { int rc = allocf(e, &d.W.g, d.W.n); if (rc) return rc; }
-        if (!d.B.g) { int rc = allocf(e, &d.B.g, d.B.n); if (rc) return rc; }
-        hipLaunchKernelGGL(pvk_dense_bwd<PV_MODE_GRAD>, dim3(d.kin / 32), dim3(256), lds_dense_bwd(d.nout), e->stream, in,
-                           d.kin, d.W.w, d.W.g, (float*)nullptr, d.B.w, d.B.g, (float*)nullptr, d.nout, d.act, Y, dY, dIn,
-                           e->st, e->adam);
-    } else {
-        hipLaunchKernelGGL(pvk_dense_bwd<PV_MODE_TRAIN>, dim3(d.kin / 32), dim3(256), lds_dense_bwd(d.nout), e->stream, in,
-                           d.kin, d.W.w, d.W.m, d.W.v, d.B.w, d.B.m, d.B.v, d.nout, d.act, Y, dY, dIn, e->st, e->adam);
-    }
+int run_dense_bwd(pvae_engine* e, Dense& d, const float* Y, const float* dY, float* dIn, float* dpre_out) {
+    hipLaunchKernelGGL(pvk_dense_bwd, dim3(d.kin / 32), dim3(256), lds_dense_bwd(d.nout), e->stream, d.kin, d.W.w, d.nout,
+                       d.act, Y, dY, dIn, dpre_out, e->st);
     return launch_check(e, "dense_bwd");
 }
 
@@ -576,27 +567,43 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
     {
         Timer t(e, C_NARROW_BWD);
         const int D = e->D;
-        // decoder hidden layers D-1..1 (elu) then layer 0 (linear): dY ping-pongs between xch1/dA/dB
+        if (km == PV_MODE_GRAD && !e->d_bwd_ops_grad) {
+            int rc2 = 0;
+            for_each_buf(e, [&](Buf3& b) { if (!rc2 && !b.g) rc2 = allocf(e, &b.g, b.n); });
+            if (rc2) return rc2;
+            if ((rc = build_bwd_ops(e, true, &e->d_bwd_ops_grad))) return rc;
+        }
+        // the chain: per layer dpre (kept in dpre_bufs, in op-table order) and dIn; dY ping-pongs between xch1/dA/dB
         const float* dY = e->xch1;
         float* bufs[2] = {e->dA, e->dB};
         int pp = 0;
+        size_t li = 0;
         for (int i = D - 1; i >= 1; --i) {
-            if ((rc = run_dense_bwd(e, e->dec[i], e->g[i - 1], e->g[i], dY, bufs[pp], km))) return rc;
+            if ((rc = run_dense_bwd(e, e->dec[i], e->g[i], dY, bufs[pp], e->dpre_bufs[li++]))) return rc;
             dY = bufs[pp];
             pp ^= 1;
         }
-        if ((rc = run_dense_bwd(e, e->dec[0], e->z, e->g[0], dY, e->dz, km))) return rc;
+        if ((rc = run_dense_bwd(e, e->dec[0], e->g[0], dY, e->dz, e->dpre_bufs[li++]))) return rc;
         hipLaunchKernelGGL(pvk_reparam_bwd, dim3(1), dim3(64), 0, e->stream, e->headout, e->Kh, e->K, e->eps, e->dz, e->Kz,
                            e->dheads, e->st);
         if ((rc = launch_check(e, "reparam_bwd"))) return rc;
-        if ((rc = run_dense_bwd(e, e->heads, e->h[D - 1], e->headout, e->dheads, bufs[pp], km))) return rc;
+        if ((rc = run_dense_bwd(e, e->heads, e->headout, e->dheads, bufs[pp], e->dpre_bufs[li++]))) return rc;
         dY = bufs[pp];
         pp ^= 1;
         for (int i = D - 2; i >= 0; --i) {
-            if ((rc = run_dense_bwd(e, e->enc[i], e->h[i], e->h[i + 1], dY, bufs[pp], km))) return rc;
+            if ((rc = run_dense_bwd(e, e->enc[i], e->h[i + 1], dY, bufs[pp], e->dpre_bufs[li++]))) return rc;
             dY = bufs[pp];
             pp ^= 1;
         }
+        // weight / bias gradients + Adam of all narrow layers: one launch, one wave per 32x32 block
+        const int maxb = (e->Wp / 32) * (e->Wp / 32);
+        if (km == PV_MODE_GRAD)
+            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_GRAD>, dim3(maxb, e->n_bwd_ops), dim3(64), 0, e->stream, e->d_bwd_ops_grad,
+                               e->st, e->adam);
+        else
+            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN>, dim3(maxb, e->n_bwd_ops), dim3(64), 0, e->stream, e->d_bwd_ops,
+                               e->st, e->adam);
+        if ((rc = launch_check(e, "narrow_adam"))) return rc;
         // first (wide) layer: dpre1 + b1
         if (km == PV_MODE_GRAD) {
             if (!e->b1.g && (rc = allocf(e, &e->b1.g, e->b1.n))) return rc;
@@ -925,10 +932,8 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     CK(ensure_loss(e, 1024));
     e->fused_narrow = e->Wp <= 128 && 2 * e->D + 2 <= PVN_MAXOPS && !getenv("PVAE_NO_FUSED_NARROW");
     e->narrow_warm = !getenv("PVAE_NO_NARROW_WARM");
-    if (e->fused_narrow) {
-        CK(build_fwd_ops(e));
-        CK(build_bwd_ops(e, false, &e->d_bwd_ops));
-    }
+    if (e->fused_narrow) CK(build_fwd_ops(e));
+    CK(build_bwd_ops(e, false, &e->d_bwd_ops));
     HK(hipStreamSynchronize(e->stream));
 #undef CK
 #undef HK

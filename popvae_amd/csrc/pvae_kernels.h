@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -246,12 +248,24 @@ __global__ __launch_bounds__(256) void pvk_dense_fwd(const float* __restrict__ i
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int kper = K / 4;
-    for (int k = wave * kper; k < (wave + 1) * kper; k += 2) {
-        const float a = in_s[c * (K + 1) + k + h];
-        const float b = Wt[(int64_t)(k + h) * N + n0 + c];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
+    const int kper = K / 4;  // multiple of 8
+    // 4 MFMA steps (8 k) per group, all operand loads of a group issued before its MFMAs; a load inside a
+    // rolled loop is waited for every iteration (one L2 round trip per MFMA)
+    auto run = [&](auto G) {
+        constexpr int S = decltype(G)::value;  // MFMA steps per group
+        for (int k = wave * kper; k < (wave + 1) * kper; k += 2 * S) {
+            float a[S], b[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                a[s] = in_s[c * (K + 1) + k + 2 * s + h];
+                b[s] = Wt[(int64_t)(k + 2 * s + h) * N + n0 + c];
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+        }
+    };
+    if (kper % 32 == 0) run(std::integral_constant<int, 16>{});
+    else run(std::integral_constant<int, 4>{});
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
@@ -265,18 +279,16 @@ __global__ __launch_bounds__(256) void pvk_dense_fwd(const float* __restrict__ i
 }
 
 // ---------------------------------------------------------------------------------------------
-// Narrow dense layer backward + Adam.  grid = K/32 workgroups (one per 32 input units = 32 rows of Wt).
-//   dpre = dY * act'(Y);  dIn[:, k-block] = dpre * Wt[k-block,:]^T (pre-update weights);
-//   dWt[k-block,:] = in[:, k-block]^T * dpre -> Adam;  workgroup 0 also does the bias.
-// MODE_GRAD writes raw gradients to gW/gB instead of updating.
+// Narrow dense layer backward, chain part (widths above 128).  grid = K/32 workgroups (one per 32 input units):
+//   dpre = dY * act'(Y)  (workgroup 0 also writes it to dpre_out for pvk_narrow_adam);
+//   dIn[:, k-block] = dpre * Wt[k-block,:]^T.
+// The weight / bias gradients and Adam run afterwards in pvk_narrow_adam (pvae_narrow.h), one wave per 32x32
+// weight block over the whole chip, for all layers in one launch.
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(256) void pvk_dense_bwd(const float* __restrict__ in, int K, float* __restrict__ Wt,
-                                                     float* __restrict__ mW, float* __restrict__ vW,
-                                                     float* __restrict__ bias, float* __restrict__ mB,
-                                                     float* __restrict__ vB, int N, int act,
+__global__ __launch_bounds__(256) void pvk_dense_bwd(int K, const float* __restrict__ Wt, int N, int act,
                                                      const float* __restrict__ Y, const float* __restrict__ dY,
-                                                     float* __restrict__ dIn, const PvStep* st, PvAdam adam) {
+                                                     float* __restrict__ dIn, float* __restrict__ dpre_out,
+                                                     const PvStep* st) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ld = N + 1;
     float* dp_s = smem;             // [32][N+1]
@@ -285,74 +297,54 @@ __global__ __launch_bounds__(256) void pvk_dense_bwd(const float* __restrict__ i
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int k0 = blockIdx.x * 32;
     const int nrows = st->nrows;
-    const float alpha = st->alpha;
-    for (int i = tid; i < 32 * N; i += 256) {
-        const int b = i / N, n = i % N;
-        float d = b < nrows ? dY[i] : 0.f;
-        if (act == PV_ACT_ELU) d *= pv_elu_grad_from_out(Y[i]);
-        dp_s[b * ld + n] = d;
-        w_s[b * ld + n] = Wt[(int64_t)(k0 + b) * N + n];
+    for (int i0 = tid; i0 < 32 * N; i0 += 1024) {
+        float yv[4], dv[4], wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // loads of 4 iterations in flight together
+            const int i = i0 + u * 256;
+            const int b = i / N, n = i % N;
+            dv[u] = dY[i];
+            yv[u] = act == PV_ACT_ELU ? Y[i] : 1.f;
+            wv[u] = Wt[(int64_t)(k0 + b) * N + n];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256;
+            const int b = i / N, n = i % N;
+            float d = b < nrows ? dv[u] : 0.f;
+            if (act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[u]);
+            dp_s[b * ld + n] = d;
+            w_s[b * ld + n] = wv[u];
+            if (blockIdx.x == 0) dpre_out[i] = d;
+        }
     }
     __syncthreads();
-    if (dIn) {
-        f32x16 acc;
+    f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const int nper = N / 4;  // N is a multiple of 32
-        for (int n = wave * nper; n < (wave + 1) * nper; n += 2) {
-            const float a = dp_s[c * ld + n + h];   // A[i=b][k=n]
-            const float b = w_s[c * ld + n + h];    // B[k=n][j=k_loc]
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nper = N / 4;  // multiple of 8
+    auto run = [&](auto G) {
+        constexpr int S = decltype(G)::value;
+        for (int n = wave * nper; n < (wave + 1) * nper; n += 2 * S) {
+            float a[S], b[S];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
-        __syncthreads();
-        for (int e = tid; e < 1024; e += 256) {
-            const float s = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
-            const int r = e >> 6, l = e & 63;
-            dIn[PV_ROW(r, l >> 5) * K + k0 + (l & 31)] = s;
-        }
-    }
-    // dWt fragments: M = k_loc, N = n, K = b
-    for (int nb = wave; nb < N / 32; nb += 4) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float a = in[(2 * s + h) * K + k0 + c];
-            const float b = dp_s[(2 * s + h) * ld + nb * 32 + c];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kl = PV_ROW(r, h);
-            const int64_t idx = (int64_t)(k0 + kl) * N + nb * 32 + c;
-            if (MODE == PV_MODE_GRAD) {
-                mW[idx] = acc[r];
-            } else {
-                float w = w_s[kl * ld + nb * 32 + c], m = mW[idx], v = vW[idx];
-                pv_adam(w, m, v, acc[r], alpha, adam);
-                Wt[idx] = w;
-                mW[idx] = m;
-                vW[idx] = v;
+            for (int s = 0; s < S; ++s) {
+                a[s] = dp_s[c * ld + n + 2 * s + h];  // A[i=b][k=n]
+                b[s] = w_s[c * ld + n + 2 * s + h];   // B[k=n][j=k_loc]
             }
+#pragma unroll
+            for (int s = 0; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
         }
-    }
-    if (blockIdx.x == 0 && bias) {
-        for (int n = tid; n < N; n += 256) {
-            float g = 0.f;
-            for (int b = 0; b < 32; ++b) g += dp_s[b * ld + n];
-            if (MODE == PV_MODE_GRAD) {
-                mB[n] = g;
-            } else {
-                float w = bias[n], m = mB[n], v = vB[n];
-                pv_adam(w, m, v, g, alpha, adam);
-                bias[n] = w;
-                mB[n] = m;
-                vB[n] = v;
-            }
-        }
+    };
+    if (nper % 32 == 0) run(std::integral_constant<int, 16>{});
+    else run(std::integral_constant<int, 4>{});
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+        const float s = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+        const int r = e >> 6, l = e & 63;
+        dIn[PV_ROW(r, l >> 5) * K + k0 + (l & 31)] = s;
     }
 }
 

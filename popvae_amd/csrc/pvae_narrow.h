@@ -500,8 +500,8 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, part 2: weight / bias gradients of every narrow dense layer + Adam.  grid = (16, n_ops), one wave
-// per 32x32 block (kb, nb) of a layer's kernel:  dW[k][n] = sum_b in[b][k] dpre[b][n]  (M = k, N = n, K = b).
+// backward, part 2: weight / bias gradients of every narrow dense layer + Adam.  grid = (max blocks, n_ops), one
+// wave per 32x32 block (kb, nb) of a layer's kernel:  dW[k][n] = sum_b in[b][k] dpre[b][n]  (M = k, N = n, K = b).
 // All operands come straight from global memory in 128-byte rows; the accumulator layout (lane = column n,
 // registers = rows k) is also the layout of the W / m / v loads and stores.
 // ---------------------------------------------------------------------------------------------
@@ -510,9 +510,10 @@ __global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict_
                                                       PvAdam adam) {
     const PvBwdOp op = ops[blockIdx.y];
     if (op.kind != PVN_DENSE) return;
-    const int kb = blockIdx.x >> 2, nb = blockIdx.x & 3;
     const int N = op.nout, Kin = op.kin;
-    if (kb * 32 >= Kin || nb * 32 >= N) return;
+    const int nbn = N >> 5;
+    const int kb = blockIdx.x / nbn, nb = blockIdx.x - kb * nbn;
+    if (kb * 32 >= Kin) return;
     const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
     const float alpha = st->alpha;
     const int voff = (kb * 32 + 4 * h) * N + nb * 32 + c;
