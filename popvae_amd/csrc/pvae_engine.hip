@@ -246,7 +246,7 @@ size_t lds_dense_fwd(int K) { return (size_t)(32 * (K + 1) + 4096) * 4; }
 size_t lds_dense_bwd(int N) { return (size_t)(2 * 32 * (N + 1) + 4096) * 4; }
 size_t lds_dec(int NWB) { return (size_t)(32 * (NWB * 32 + 1) + 4 * 3 * 32 * 33) * 4; }
 size_t lds_enc_bwd(int Wp) { return (size_t)32 * Wp * 4; }
-size_t lds_enc_bwd_fused(int NWB) { return std::max<size_t>((size_t)32 * NWB * 32 * 4, (size_t)4 * NWB * 1024 * 4); }
+size_t lds_enc_bwd_fused(int NWB, int Wp) { return std::max<size_t>((size_t)32 * Wp * 4, (size_t)4 * NWB * 1024 * 4); }
 size_t lds_dec_grp(int ngrp) {
     return std::max<size_t>((size_t)32 * (ngrp * 128 + 1) + 8 * 2 * 32 * 33, (size_t)8 * 4 * 1024 + 8) * 4;
 }
@@ -270,7 +270,7 @@ int setup_kernel_attrs(pvae_engine* e) {
     HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_GRAD>, lds_dec(N)));                       \
     HIPCHK(allow_lds(pvk_dec<N, 0, PV_MODE_TRAIN>, lds_dec(N)));                      \
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN, 0>), lds_enc_bwd(e->Wp)));        \
-    HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN, 1>), lds_enc_bwd_fused(N)));      \
+    HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN, 1>), lds_enc_bwd_fused(N, e->Wp)));  \
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_GRAD, 0>), lds_enc_bwd(e->Wp)));
     switch (e->NWB) {
         case 1: PV_ATTR(1) break;
@@ -331,8 +331,8 @@ int stage_a(pvae_engine* e, int row_offset, bool need_xt, bool fwd_done = false)
     }
     if (fwd_done) {
         // the previous step's pvk_enc_bwd<.., FUSE = 1> already left this batch's partial sums in encpart
-        hipLaunchKernelGGL(pvk_reduce_parts, dim3(32 * e->Wp / 64), dim3(256), 0, e->stream, e->encpart, e->encb_wgs, 32 * e->Wp,
-                           0.5f, e->P, (const float*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(32 * e->Wp / 64), dim3(256), 0, e->stream, e->encpart, e->encb_wgs / e->ngrp,
+                           32 * e->Wp, 0.5f, e->P, (const float*)nullptr, (float*)nullptr);
         if ((rc = launch_check(e, "enc_reduce"))) return rc;
     } else {
         Timer t(e, C_ENC_FWD);
@@ -514,7 +514,7 @@ int enc_bwd_launch(pvae_engine* e, int km, bool fuse = false, int next_off = 0, 
                                               e->ngrp, e->st, e->adam, nog, (int64_t)0, nor, 0, 0, nof, e->ts4));
     } else if (fuse) {
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 1>), dim3(e->encb_wgs), dim3(256),
-                                              lds_enc_bwd_fused(N_), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
+                                              lds_enc_bwd_fused(N_, e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
                                               e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam,
                                               (const uint8_t*)e->geno, e->row_bytes, (const int*)e->d_rows, next_off, next_n,
                                               e->encpart, e->ts4));
@@ -882,7 +882,6 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     HK(hipMalloc(&e->Xt, e->Lp * sizeof(uint64_t)));
     HK(hipMemsetAsync(e->Xt, 0, e->Lp * sizeof(uint64_t), e->stream));
 
-    const int64_t tasks = (int64_t)e->nblk * e->ngrp;
     auto clampi = [](int64_t v, int64_t lo, int64_t hi) { return (int)std::min(hi, std::max(lo, v)); };
     CK(setup_kernel_attrs(e));
     // the wide kernels are persistent-style: the grid is exactly what is co-resident (CUs x blocks per CU), so that
@@ -900,8 +899,8 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
                 HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, pvk_dec_grp<2, 1, PV_MODE_TRAIN>, 512, lds_dec_grp(2)));
             else
                 HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, pvk_dec_grp<4, 1, PV_MODE_TRAIN>, 512, lds_dec_grp(4)));
-            if (e->ngrp == 1 && !getenv("PVAE_NO_FUSE_FWD"))
-                HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_encb, (pvk_enc_bwd<N_, PV_MODE_TRAIN, 1>), 256, lds_enc_bwd_fused(N_)));
+            if (!getenv("PVAE_NO_FUSE_FWD"))
+                HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_encb, (pvk_enc_bwd<N_, PV_MODE_TRAIN, 1>), 256, lds_enc_bwd_fused(N_, e->Wp)));
             else
                 HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_encb, (pvk_enc_bwd<N_, PV_MODE_TRAIN, 0>), 256, lds_enc_bwd(e->Wp)));
         });
@@ -911,13 +910,13 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
         o_encb = envi("PVAE_ENCB_OCC", std::max(o_encb, 1));
         e->enc_wgs = clampi((e->nblk + 3) / 4, 1, (int64_t)cus * o_enc / e->ngrp) * e->ngrp;  // multiple of ngrp
         e->dec_wgs = clampi((e->nblk + 3) / 4, 1, (int64_t)cus * o_dec);
-        e->encb_wgs = clampi((tasks + 3) / 4, 1, (int64_t)cus * o_encb);
+        e->encb_wgs = clampi((e->nblk + 3) / 4, 1, (int64_t)cus * o_encb / e->ngrp) * e->ngrp;  // multiple of ngrp
         if (getenv("PVAE_VERBOSE"))
             fprintf(stderr, "[pvae] CUs %d; blocks/CU enc_fwd %d dec %d enc_bwd %d; grids %d %d %d\n", cus, o_enc, o_dec, o_encb,
                     e->enc_wgs, e->dec_wgs, e->encb_wgs);
     }
     CK(allocf(e, &e->encpart, (int64_t)std::max(e->enc_wgs, e->encb_wgs) * e->NWB * 1024));
-    e->fuse_fwd = e->ngrp == 1 && !getenv("PVAE_NO_FUSE_FWD");
+    e->fuse_fwd = !getenv("PVAE_NO_FUSE_FWD");
     CK(allocf(e, &e->dgpart, (int64_t)e->dec_wgs * 32 * e->Wp));
     CK(allocf(e, &e->losspart, (int64_t)e->dec_wgs));
 

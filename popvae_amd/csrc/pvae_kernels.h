@@ -888,7 +888,7 @@ __global__ void pvk_loss_final(const float* __restrict__ recon, const float* __r
 // Wide encoder backward + Adam: dW1[l][u] = 0.5 * sum_b code(b,l) * dpre1[b][u]; M = l, N = u, K = b.
 // One wave per subtile; dpre1 staged once per workgroup in LDS.
 // ---------------------------------------------------------------------------------------------
-// FUSE = 1 (ngrp == 1 only): the freshly updated tile, still in registers, is also multiplied with the NEXT
+// FUSE = 1: the freshly updated tile, still in registers, is also multiplied with the NEXT
 // batch's genotype codes -- the next step's first-layer forward (pvk_enc_fwd) rides along, which saves one
 // full read of W1 (4 of the 52 bytes per wide parameter and step).  Partials go to fpart[workgroup][32][Wp]
 // exactly as pvk_enc_fwd writes them.
@@ -904,14 +904,16 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
     constexpr int WG_UNITS = NWB * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [ngrp][32][WG_UNITS]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
-    const int gw = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    // a workgroup stays on ONE unit group (grp = blockIdx.x % ngrp; gridDim.x is a multiple of ngrp): its waves'
+    // forward fragments (FUSE) can then be summed, and neighbouring workgroups still sweep one window of HBM
+    const int grp = blockIdx.x % ngrp;
+    const int slot = (blockIdx.x / ngrp) * 4 + wave, nslots = (gridDim.x / ngrp) * 4;
     const float alpha = st->alpha;
     for (int i = tid; i < 32 * ldp; i += 256) {
         const int b = i / ldp, u = i % ldp;
         smem[((u / WG_UNITS) * 32 + b) * WG_UNITS + (u % WG_UNITS)] = dpre[i];
     }
     __syncthreads();
-    const int64_t ntasks = (int64_t)nblk * ngrp;
     const uint8_t* nrow = nullptr;  // FUSE: lane c's sample of the next batch
     f32x16 facc[NWB];
     if (FUSE) {
@@ -921,8 +923,8 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) facc[w][r] = 0.f;
     }
-    for (int64_t t = gw; t < ntasks; t += nwaves) {  // round-robin, see pvk_dec
-        const int blk = (int)(t / ngrp), grp = (int)(t % ngrp);
+    for (int blk = slot; blk < nblk; blk += nslots) {  // round-robin, see pvk_dec
+        const int64_t t = (int64_t)blk * ngrp + grp;
         uint32_t nlo = 0, nhi = 0;
         if (FUSE) {
             uint64_t xn = nrow ? *reinterpret_cast<const uint64_t*>(nrow + (int64_t)blk * 8) : 0ull;
@@ -990,11 +992,12 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[((wave * NWB + w) * 16 + r) * 64 + lane] = facc[w][r];
         __syncthreads();
-        float* p = fpart + (int64_t)blockIdx.x * (NWB * 1024);
+        const int ldf = ngrp * NWB * 32;
+        float* p = fpart + (int64_t)(blockIdx.x / ngrp) * (32 * ldf) + grp * (NWB * 32);
         for (int e = tid; e < NWB * 1024; e += 256) {
             const float sum = ((red[e] + red[NWB * 1024 + e]) + red[2 * NWB * 1024 + e]) + red[3 * NWB * 1024 + e];
             const int w = e >> 10, r = (e >> 6) & 15, ln = e & 63;
-            p[PV_ROW(r, ln >> 5) * (NWB * 32) + w * 32 + (ln & 31)] = sum;
+            p[PV_ROW(r, ln >> 5) * ldf + w * 32 + (ln & 31)] = sum;
         }
     }
 }
