@@ -52,8 +52,8 @@ struct TensorRef {
     int64_t rows, cols;  // Keras shape (cols = 0 for bias)
 };
 
-enum Cat { C_GATHER, C_ENC_FWD, C_NARROW_FWD, C_DEC, C_NARROW_BWD, C_ENC_BWD, C_NCAT };
-const char* kCatNames[C_NCAT] = {"gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd"};
+enum Cat { C_GATHER, C_ENC_FWD, C_NARROW_FWD, C_DEC, C_NARROW_BWD, C_ENC_BWD, C_APPLY, C_NCAT };
+const char* kCatNames[C_NCAT] = {"gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd", "apply"};
 
 }  // namespace
 
@@ -645,6 +645,8 @@ constexpr size_t kSlotBytes = 32 * sizeof(int) + 32 * 16 * sizeof(float);
 int begin_batch(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, bool train) {
     int rc;
     if (n <= 0 || n > e->cfg.batch_size) return set_err(e, -2, "batch of %d rows (batch_size %d)", n, e->cfg.batch_size);
+    if (n > 32) return set_err(e, -2, "a device pass takes at most 32 rows (got %d): larger batches go through pvae_train_step / "
+                                      "pvae_train_epoch, which tile them", n);
     if (!e->geno) return set_err(e, -3, "no genotypes loaded (pvae_load_genotypes)");
     if ((rc = check_rows(e, rows, n))) return rc;
     if ((rc = ensure_rows(e, n))) return rc;
@@ -682,16 +684,70 @@ int fetch_out3(pvae_engine* e, float* out3) {
     return 0;
 }
 
+// Adam from the accumulated gradient buffers (batches above 32 rows): wide tensors stream copy -> copy like a
+// train step does, the narrow ones update in place
+int apply_gradients(pvae_engine* e) {
+    Timer t(e, C_APPLY);
+    int rc = 0;
+    for_each_buf(e, [&](Buf3& b) {
+        if (rc) return;
+        if (!b.g) { rc = set_err(e, -6, "apply_gradients: no gradient buffer"); return; }
+        if (b.il_tile) {
+            hipLaunchKernelGGL(pvk_apply_wide, dim3(2048), dim3(256), 0, e->stream, (const f32x4*)b.w, (f32x4*)b.w2,
+                               (const f32x4*)b.g, b.n / b.il_tile, (int)(b.il_tile / 4), e->st, e->adam);
+            b.swap();
+        } else {
+            hipLaunchKernelGGL(pvk_apply_lin, dim3((unsigned)std::min<int64_t>((b.n + 255) / 256, 1024)), dim3(256), 0, e->stream, b.w,
+                               b.m, b.v, b.g, b.n, e->st, e->adam);
+        }
+    });
+    return rc ? rc : launch_check(e, "apply_gradients");
+}
+
+// one 32-row tile of a larger batch (rows already on the device at d_rows[row_offset..]): forward, loss part,
+// gradients stored (first tile) or added (later tiles); inv_b is 1 / (rows of the WHOLE batch), so that the
+// tiles' loss parts and gradients add up to the batch mean
+int run_tile(pvae_engine* e, int row_offset, int nrows, int n_batch, int tile, bool eval, float* d_out3) {
+    int rc;
+    hipLaunchKernelGGL(pvk_tile_begin, dim3(1), dim3(64), 0, e->stream, e->st, nrows, 1.f / (float)n_batch, tile > 0 ? 1 : 0);
+    if ((rc = launch_check(e, "tile_begin"))) return rc;
+    if ((rc = stage_a(e, row_offset, true))) return rc;
+    if ((rc = stage_b(e, eval ? 1 : 2))) return rc;
+    return stage_c(e, eval ? 1 : 2, d_out3);
+}
+
 int full_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3, int mode) {
     int rc;
     if (e->cfg.world != 1)
         return set_err(e, -5, "world > 1: drive the step through pvae_stage_a/b/c with all-reduces in between");
-    if ((rc = ensure_loss(e, 1))) return rc;
-    if ((rc = begin_batch(e, rows, n, eps, mode == 0))) return rc;
-    if ((rc = stage_a(e, 0, true))) return rc;
-    if ((rc = stage_b(e, mode))) return rc;
-    if ((rc = stage_c(e, mode, e->d_loss))) return rc;
-    return fetch_out3(e, out3);
+    if (n <= 0 || n > e->cfg.batch_size) return set_err(e, -2, "batch of %d rows (batch_size %d)", n, e->cfg.batch_size);
+    if (n <= 32) {
+        if ((rc = ensure_loss(e, 1))) return rc;
+        if ((rc = begin_batch(e, rows, n, eps, mode == 0))) return rc;
+        if ((rc = stage_a(e, 0, true))) return rc;
+        if ((rc = stage_b(e, mode))) return rc;
+        if ((rc = stage_c(e, mode, e->d_loss))) return rc;
+        return fetch_out3(e, out3);
+    }
+    const int nt = (n + 31) / 32;
+    if ((rc = ensure_loss(e, nt))) return rc;
+    for (int t = 0; t < nt; ++t) {
+        const int nb = std::min(32, n - 32 * t);
+        // begin_batch uploads this tile's rows (+ eps) and, on the first tile of a train step, advances Adam's t
+        if ((rc = begin_batch(e, rows + 32 * t, nb, eps ? eps + (size_t)32 * t * e->K : nullptr, mode == 0 && t == 0))) return rc;
+        if ((rc = run_tile(e, 0, nb, n, t, mode == 1, e->d_loss + 3 * t))) return rc;
+    }
+    if (mode == 0 && (rc = apply_gradients(e))) return rc;
+    std::vector<float> hl((size_t)nt * 3);
+    HIPCHK(hipMemcpyAsync(hl.data(), e->d_loss, hl.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (out3)
+        for (int c = 0; c < 3; ++c) {
+            float a = 0.f;
+            for (int t = 0; t < nt; ++t) a += hl[(size_t)t * 3 + c];
+            out3[c] = a;
+        }
+    return 0;
 }
 
 // tensor <-> storage plumbing -------------------------------------------------------------------
@@ -798,8 +854,10 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     };
     if (cfg->n_snps_local <= 0 || cfg->width <= 0 || cfg->depth < 1 || cfg->latent_dim < 1)
         return bail(set_err(e, -2, "bad dimensions"));
-    if (cfg->batch_size < 1 || cfg->batch_size > 32)
-        return bail(set_err(e, -2, "batch_size %d unsupported: this build handles 1..32 rows per step", cfg->batch_size));
+    if (cfg->batch_size < 1 || cfg->batch_size > 65536)
+        return bail(set_err(e, -2, "batch_size %d unsupported (1..65536)", cfg->batch_size));
+    if (cfg->batch_size > 32 && cfg->world > 1)
+        return bail(set_err(e, -2, "batch_size %d with SNP-axis sharding: the staged API handles 1..32 rows per step", cfg->batch_size));
     if (cfg->width > 512) return bail(set_err(e, -2, "width %d unsupported: this build handles widths up to 512", cfg->width));
     if (cfg->latent_dim > 16) return bail(set_err(e, -2, "latent_dim %d unsupported (max 16)", cfg->latent_dim));
     int ndev = 0;
@@ -1082,12 +1140,30 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
     if ((rc = check_rows(e, perm, n_train))) return rc;
     if (n_val > 0 && (rc = check_rows(e, val_rows, n_val))) return rc;
     if ((rc = ensure_rows(e, (int64_t)n_train + std::max(n_val, 0)))) return rc;
-    if ((rc = ensure_loss(e, st_tr + st_va))) return rc;
+    if ((rc = ensure_loss(e, (int64_t)(st_tr + st_va) * ((B + 31) / 32)))) return rc;
     HIPCHK(hipMemcpyAsync(e->d_rows, perm, (size_t)n_train * sizeof(int), hipMemcpyHostToDevice, e->stream));
     if (n_val > 0)
         HIPCHK(hipMemcpyAsync(e->d_rows + n_train, val_rows, (size_t)n_val * sizeof(int), hipMemcpyHostToDevice, e->stream));
     bool fwd_done = false;
-    for (int phase = 0; phase < 2; ++phase) {
+    const int tp = (B + 31) / 32;  // 32-row tiles per batch
+    for (int phase = 0; phase < 2 && tp > 1; ++phase) {
+        // batches above 32 rows: tiles with accumulated gradients, one Adam update per batch
+        const int steps = phase == 0 ? st_tr : st_va, nt = phase == 0 ? n_train : n_val, base = phase == 0 ? 0 : n_train;
+        for (int s = 0; s < steps; ++s) {
+            const int nb = std::min(B, nt - s * B);
+            float* slot = e->d_loss + 3 * (size_t)((phase == 0 ? 0 : st_tr) + s) * tp;
+            HIPCHK(hipMemsetAsync(slot, 0, (size_t)3 * tp * sizeof(float), e->stream));
+            hipLaunchKernelGGL(pvk_step_begin, dim3(1), dim3(64), 0, e->stream, e->st, (const int*)nullptr, nb, B, 0, phase == 0 ? 1 : 0,
+                               e->adam.b1, e->adam.b2);
+            for (int t = 0; t * 32 < nb; ++t) {
+                hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, 32 * e->K, e->cfg.seed, e->d_counter);
+                if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
+                if ((rc = run_tile(e, base + s * B + 32 * t, std::min(32, nb - 32 * t), nb, t, phase == 1, slot + 3 * t))) return rc;
+            }
+            if (phase == 0 && (rc = apply_gradients(e))) return rc;
+        }
+    }
+    for (int phase = 0; phase < 2 && tp == 1; ++phase) {
         const int steps = phase == 0 ? st_tr : st_va;
         if (!steps) continue;
         int nt = phase == 0 ? n_train : n_val;
@@ -1113,13 +1189,14 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
             fwd_done = fuse;
         }
     }
-    std::vector<float> hl((size_t)(st_tr + st_va) * 3);
+    std::vector<float> hl((size_t)(st_tr + st_va) * tp * 3);
     HIPCHK(hipMemcpyAsync(hl.data(), e->d_loss, hl.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    // K9: plain mean of the per-batch scalars (the short last batch counts equally)
+    // K9: plain mean of the per-batch scalars (the short last batch counts equally); a batch's scalar is the sum of
+    // its tiles' parts
     double a = 0, b = 0;
-    for (int s = 0; s < st_tr; ++s) a += hl[(size_t)s * 3];
-    for (int s = 0; s < st_va; ++s) b += hl[(size_t)(st_tr + s) * 3];
+    for (int s = 0; s < st_tr * tp; ++s) a += hl[(size_t)s * 3];
+    for (int s = 0; s < st_va * tp; ++s) b += hl[(size_t)(st_tr * tp + s) * 3];
     if (loss) *loss = (float)(a / st_tr);
     if (val_loss) *val_loss = st_va ? (float)(b / st_va) : NAN;
     return 0;

@@ -41,6 +41,8 @@ struct PvStep {  // device-resident per-step scalars (graph-replay friendly)
     int nrows;    // valid rows of the current batch tile
     float inv_b;  // 1 / nrows
     int step_in_epoch;
+    int acc;      // gradient dumps (MODE_GRAD): 0 = store, 1 = add to what is there (batches above 32 rows are
+                  // processed as 32-row tiles whose gradients are accumulated before ONE Adam update)
 };
 
 struct PvAdam {
@@ -79,6 +81,7 @@ __global__ void pvk_step_begin(PvStep* st, const int* __restrict__ n_total_ptr, 
         st->nrows = nrows;
         st->inv_b = nrows > 0 ? 1.f / (float)nrows : 0.f;
         st->step_in_epoch = step;
+        st->acc = 0;
         if (train) {
             int t = st->t + 1;
             st->t = t;
@@ -86,6 +89,15 @@ __global__ void pvk_step_begin(PvStep* st, const int* __restrict__ n_total_ptr, 
             float b1p = powf(b1, (float)t), b2p = powf(b2, (float)t);
             st->alpha = st->lr * sqrtf(1.f - b2p) / (1.f - b1p);
         }
+    }
+}
+
+// one 32-row tile of a larger batch: rows of this tile, 1/B of the WHOLE batch, accumulate flag
+__global__ void pvk_tile_begin(PvStep* st, int nrows, float inv_b_total, int acc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        st->nrows = nrows;
+        st->inv_b = inv_b_total;
+        st->acc = acc;
     }
 }
 
@@ -365,7 +377,7 @@ __global__ void pvk_bias_bwd(const float* __restrict__ Y, const float* __restric
         g += d;
     }
     if (MODE == PV_MODE_GRAD) {
-        mB[n] = g;
+        mB[n] = st->acc ? mB[n] + g : g;
     } else {
         float w = bias[n], m = mB[n], v = vB[n];
         pv_adam(w, m, v, g, st->alpha, adam);
@@ -441,6 +453,7 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
     const int gw = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
+    const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
 
     for (int i = tid; i < 32 * WP; i += 256) g_s[(i / WP) * LDG + (i % WP)] = g[i];
     __syncthreads();
@@ -508,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
             dbias += __shfl_xor(dbias, 32);
             if (h == 0 && lvalid) {
                 if (MODE == PV_MODE_GRAD) {
-                    mC[l] = dbias;
+                    mC[l] = acc_grads ? mC[l] + dbias : dbias;
                 } else {
                     float w_ = bias, m_ = mC[l], v_ = vC[l];
                     pv_adam(w_, m_, v_, dbias, alpha, adam);
@@ -558,6 +571,7 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
                     const int off = (w * 4 + q) * 64 + lane;
                     if (MODE == PV_MODE_GRAD) {
                         f32x4 gq = {dv[q * 4 + 0], dv[q * 4 + 1], dv[q * 4 + 2], dv[q * 4 + 3]};
+                        if (acc_grads) gq += dM2[off];
                         dM2[off] = gq;
                     } else {
                         f32x4 wq = vv[w][q], mq = __builtin_nontemporal_load(tM + off), vq = __builtin_nontemporal_load(tVv + off);
@@ -637,6 +651,7 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
     const int per = (bgroups + gridDim.x - 1) / gridDim.x;
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
+    const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
 
     for (int i = tid; i < 32 * WP; i += 512) g_s[(i / WP) * LDG + (i % WP)] = g[i];
     __syncthreads();
@@ -718,7 +733,7 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
             dbias += __shfl_xor(dbias, 32);
             if (grp == 0 && h == 0 && lvalid) {
                 if (MODE == PV_MODE_GRAD) {
-                    mC[l] = dbias;
+                    mC[l] = acc_grads ? mC[l] + dbias : dbias;
                 } else {
                     float w_ = bias, m_ = mC[l], v_ = vC[l];
                     pv_adam(w_, m_, v_, dbias, alpha, adam);
@@ -767,6 +782,7 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
                     const int off = (w * 4 + q) * 64 + lane;
                     if (MODE == PV_MODE_GRAD) {
                         f32x4 gq = {dv[q * 4 + 0], dv[q * 4 + 1], dv[q * 4 + 2], dv[q * 4 + 3]};
+                        if (acc_grads) gq += dM2[off];
                         dM2[off] = gq;
                     } else {
                         f32x4 wq = vv[w][q], mq = __builtin_nontemporal_load(tM + off), vq = __builtin_nontemporal_load(tVv + off);
@@ -909,6 +925,7 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
     const int grp = blockIdx.x % ngrp;
     const int slot = (blockIdx.x / ngrp) * 4 + wave, nslots = (gridDim.x / ngrp) * 4;
     const float alpha = st->alpha;
+    const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
     for (int i = tid; i < 32 * ldp; i += 256) {
         const int b = i / ldp, u = i % ldp;
         smem[((u / WG_UNITS) * 32 + b) * WG_UNITS + (u % WG_UNITS)] = dpre[i];
@@ -959,6 +976,7 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
                 const int off = (w * 4 + q) * 64 + lane;
                 if (MODE == PV_MODE_GRAD) {
                     f32x4 gq = {0.5f * dw[q * 4 + 0], 0.5f * dw[q * 4 + 1], 0.5f * dw[q * 4 + 2], 0.5f * dw[q * 4 + 3]};
+                    if (acc_grads) gq += oM[off];
                     oM[off] = gq;
                 } else {
                     f32x4 wq = __builtin_nontemporal_load(tW + off), mq = __builtin_nontemporal_load(tM + off),
@@ -999,6 +1017,41 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
             const int w = e >> 10, r = (e >> 6) & 15, ln = e & 63;
             p[PV_ROW(r, ln >> 5) * ldf + w * 32 + (ln & 31)] = sum;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam from accumulated gradients (batches above 32 rows).  Wide tensors: tile-interleaved W|m|v copy `cur` ->
+// copy `nxt`, gradient in plain tiles; linear tensors in place.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pvk_apply_wide(const f32x4* __restrict__ cur, f32x4* __restrict__ nxt,
+                                                      const f32x4* __restrict__ g, int64_t ntiles, int tile4,
+                                                      const PvStep* st, PvAdam adam) {
+    const float alpha = st->alpha;
+    const int64_t n4 = ntiles * tile4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / tile4, o = t * 3 * tile4 + (i - t * tile4);
+        f32x4 w = __builtin_nontemporal_load(cur + o), m = __builtin_nontemporal_load(cur + o + tile4),
+              v = __builtin_nontemporal_load(cur + o + 2 * tile4), gq = __builtin_nontemporal_load(g + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float w_ = w[e], m_ = m[e], v_ = v[e];
+            pv_adam(w_, m_, v_, gq[e], alpha, adam);
+            w[e] = w_; m[e] = m_; v[e] = v_;
+        }
+        __builtin_nontemporal_store(w, nxt + o);
+        __builtin_nontemporal_store(m, nxt + o + tile4);
+        __builtin_nontemporal_store(v, nxt + o + 2 * tile4);
+    }
+}
+
+__global__ __launch_bounds__(256) void pvk_apply_lin(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                     const float* __restrict__ g, int64_t n, const PvStep* st, PvAdam adam) {
+    const float alpha = st->alpha;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float w_ = w[i], m_ = m[i], v_ = v[i];
+        pv_adam(w_, m_, v_, g[i], alpha, adam);
+        w[i] = w_; m[i] = m_; v[i] = v_;
     }
 }
 

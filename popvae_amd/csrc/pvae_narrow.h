@@ -464,7 +464,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
 #pragma unroll 8
                 for (int b = 0; b < 32; ++b) g += dp_s[b * PVN_LD + tid];
                 if (MODE == PV_MODE_GRAD) {
-                    op.mB[tid] = g;
+                    op.mB[tid] = st->acc ? op.mB[tid] + g : g;
                 } else {
                     float w_ = op.B[tid], m_ = op.mB[tid], v_ = op.vB[tid];
                     pv_adam(w_, m_, v_, g, alpha, adam);
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict_
     for (int r = 0; r < 16; ++r) {
         const int ro = ((r & 3) + 8 * (r >> 2)) * N;
         if (MODE == PV_MODE_GRAD) {
-            (op.mW + ro)[voff] = acc[r];
+            (op.mW + ro)[voff] = st->acc ? (op.mW + ro)[voff] + acc[r] : acc[r];
         } else {
             float w_ = wv[r], m_ = mv[r], v_ = vv[r];
             pv_adam(w_, m_, v_, acc[r], alpha, adam);
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict_
 #pragma unroll
         for (int s = 0; s < 32; ++s) g += op.dpre[s * N + n];
         if (MODE == PV_MODE_GRAD) {
-            op.mB[n] = g;
+            op.mB[n] = st->acc ? op.mB[n] + g : g;
         } else {
             float w_ = op.B[n], m_ = op.mB[n], v_ = op.vB[n];
             pv_adam(w_, m_, v_, g, alpha, adam);
