@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel-level timing at a BASELINE shape without torch: python tools/kbench.py [C4|C2] [steps]
+"""Kernel-level timing at a BASELINE shape without torch: python tools/kbench.py [C4|C2] [steps] [batch_size]
 Prints per-kernel-category HIP-event averages and the implied GB/s."""
 import os
 import sys
@@ -15,6 +15,7 @@ SH = {"C4": (2504, 1_000_000, 128, 6), "C2": (1000, 100_000, 128, 6), "C1": (95,
 name = sys.argv[1] if len(sys.argv) > 1 else "C4"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 N, L, W, D = SH[name]
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 g = np.random.default_rng(0)
 lut = np.arange(256, dtype=np.uint8)
 for sh in (0, 2, 4, 6):
@@ -25,29 +26,29 @@ packed = lut[g.integers(0, 256, size=(N, rb), dtype=np.uint8)]
 if L % 32:
     packed[:, L // 4 + 1:] = 0
     packed[:, L // 4] &= (1 << (2 * (L % 4))) - 1
-e = E.Engine(n_snps=L, width=W, depth=D, latent_dim=2, batch_size=32, seed=1)
+e = E.Engine(n_snps=L, width=W, depth=D, latent_dim=2, batch_size=B, seed=1)
 e.load_genotypes(packed)
 e.init_weights(1)
 if os.environ.get("LR"):
     e.lr = float(os.environ["LR"])
-rows = np.concatenate([g.permutation(N) for _ in range(steps * 32 // N + 2)])[:steps * 32].astype(np.int32)
-e.train_epoch(rows[:5 * 32], np.zeros(0, np.int32))
+rows = np.concatenate([g.permutation(N) for _ in range(steps * B // N + 2)])[:steps * B].astype(np.int32)
+e.train_epoch(rows[:5 * B], np.zeros(0, np.int32))
 e.set_timing(True)
 t0 = time.perf_counter()
 loss, _ = e.train_epoch(rows, np.zeros(0, np.int32))
 dt = time.perf_counter() - t0
 Wp = (W + 31) // 32 * 32 if W <= 128 else (256 if W <= 256 else 512)
 algo = {"dec": 24 * L * Wp + 32 * L, "enc_fwd": 4 * L * Wp + 8 * L, "enc_bwd": 24 * L * Wp + 8 * L}
-print(f"{name}: {dt / steps * 1e3:.3f} ms/step  {steps * 32 / dt:.0f} samples/s  loss {loss:.3f}")
+print(f"{name} B={B}: {dt / steps * 1e3:.3f} ms/step  {steps * B / dt:.0f} samples/s  loss {loss:.3f}")
 tot = 0
-for k in ("gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd"):
+for k in ("gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd", "apply"):
     ms, n = e.get_timing(k)
     if n:
         a = ms / n
-        tot += a
+        tot += a * n / steps
         extra = f"  {algo[k] / a / 1e6:8.0f} GB/s" if k in algo else ""
-        print(f"  {k:11s} {a * 1e3:9.1f} us{extra}")
-print(f"  sum         {tot * 1e3:9.1f} us")
+        print(f"  {k:11s} {a * 1e3:9.1f} us x {n / steps:.0f}{extra}")
+print(f"  sum/step    {tot * 1e3:9.1f} us")
 vr = rows[:8 * 32].reshape(8, 32)
 e.set_timing(False)
 e.synchronize()
