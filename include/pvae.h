@@ -97,6 +97,15 @@ int pvae_encode(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
 /* decoder.predict (scripts/popvae_decoder_tests_HGDP.py:156): probs [n][n_snps_local] from z [n][latent_dim] */
 int pvae_decode(pvae_engine* e, const float* z, int32_t n, float* probs);
 
+/* popvae.py:528-533: allel.pca(dc.T, scaler, n_components) = per-site scaler + SVD of the scaled N x L matrix.
+ * This entry computes, in float64 on the GPU, the per-site scaler over ALL loaded samples and the N x N Gram matrix
+ * G = Xs Xs^T of the scaled matrix (v_mfma_f64_16x16x4_f64 on the resident 2-bit matrix); the host takes
+ * G = U S^2 U^T and keeps U S (popvae_amd/pca.py).  scaler: 0 = centre only, 1 = Patterson, 2 = standard
+ * (allel get_scaler; the reference feeds VALUES code/2 with allel's default ploidy 2, reproduced as is).
+ * gram: host, n_samples^2 doubles, row-major.  site_mean / site_std: host, n_snps_local doubles, or NULL.
+ * Under SNP-axis sharding each rank gets the Gram matrix of its own columns; their sum is the global one. */
+int pvae_pca_gram(pvae_engine* e, int scaler, double* gram, double* site_mean, double* site_std);
+
 /* ModelCheckpoint(save_best_only) + load_weights (popvae.py:429-435,508): device-to-device copy of the
  * parameters (not the Adam slots) */
 int pvae_snapshot_best(pvae_engine* e);

@@ -438,3 +438,36 @@ def fit(weights, dc, train, test, D, K, batch_size, max_epochs, patience, perm_f
         if stop:
             break
     return hist, best, preds
+
+
+# ---------------------------------------------------------------------------------------------
+# PCA (popvae.py:528-533 -> allel.pca).  scikit-allel is not importable here and holds no fixture for this
+# call inside /root/reference: PARITY UNPINNED -- this restates its published algorithm
+# (allel/stats/decomposition.py, GenotypePCA + allel/stats/preprocessing.py scalers) [UPSTREAM].
+# ---------------------------------------------------------------------------------------------
+def pca_scale(gn, scaler="patterson", ploidy=2):
+    """gn: variants x samples (the reference passes dc.T with VALUES 0 / 0.5 / 1).  Returns (scaled, mean, std)."""
+    gn = np.array(gn, dtype=np.float64)
+    if isinstance(scaler, str):
+        scaler = scaler.lower()
+    mean = np.mean(gn, axis=1, keepdims=True)
+    if scaler == "patterson":
+        p = mean / ploidy
+        std = np.sqrt(p * (1 - p))
+    elif scaler == "standard":
+        std = np.std(gn, axis=1, keepdims=True)
+    else:
+        std = np.ones_like(mean)
+    gn -= mean
+    gn /= std
+    return gn, mean[:, 0], std[:, 0]
+
+
+def pca(dc_values, scaler="Patterson", n_components=20):
+    """allel.pca(dc.T, scaler, n_components)[0] for dc_values [N, L] in {0, 0.5, 1}: U[:, :n] * S[:n]."""
+    import scipy.linalg
+    gn, _, _ = pca_scale(np.asarray(dc_values).T, scaler)
+    x = gn.T
+    u, s, v = scipy.linalg.svd(x, full_matrices=False)
+    ev = (s ** 2) / x.shape[0]
+    return u[:, :n_components] * s[:n_components], (ev / np.sum(ev))[:n_components]

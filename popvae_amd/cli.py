@@ -240,14 +240,23 @@ def main(argv=None):
                 log("--save_weights: each rank holds an SNP shard; writing rank 0's shard only")
             w = eng.get_weights_shard() if world > 1 else eng.get_weights()
             log("weights saved to " + save_weights_file(args.out, w, tensor_names(depth)))
-        if args.PCA:
-            log("--PCA is outside the engine's scope (scikit-allel SVD, popvae.py:528-540); skipped")
         try:
             F.plot_history(args.out + "_history.pdf", history)
         except Exception as ex:  # matplotlib absent or headless failure: the reference's pdf is cosmetic
             log(f"history plot skipped: {ex}")
         if args.plot:
             log("--plot needs bokeh (scripts/plotvae.py in the reference); skipped")
+    if args.PCA:  # popvae.py:528-540, 561-563 (every rank contributes the Gram matrix of its own SNP columns)
+        from . import pca as P
+        t1 = time.time()
+        log("running PCA")
+        coords, _ = eng.pca(args.PCA_scaler, args.n_pc_axes) if world > 1 else P.pca(eng, args.PCA_scaler, args.n_pc_axes)
+        if rank == 0:
+            P.write_pca(args.out + "_pca.txt", coords, samples)
+        pcatime = time.time() - t1
+        log("PCA run time: " + str(pcatime) + " seconds")
+        if rank == 0:
+            np.savetxt(X=np.array([vaetime, pcatime]), fname=args.out + "_runtimes.txt")
     eng.close()
     if world > 1:
         dist.barrier()

@@ -23,6 +23,7 @@
 #include "../../include/pvae.h"
 #include "pvae_kernels.h"
 #include "pvae_narrow.h"
+#include "pvae_pca.h"
 
 #define PV_VERSION "popvae_amd 0.1.0 (gfx950)"
 
@@ -1268,6 +1269,60 @@ int pvae_decode(pvae_engine* e, const float* z, int32_t n, float* probs) {
         HIPCHK(hipStreamSynchronize(e->stream));
     }
     return 0;
+}
+
+int pvae_pca_gram(pvae_engine* e, int scaler, double* gram, double* site_mean, double* site_std) {
+    if (!e->geno) return set_err(e, -3, "no genotypes loaded (pvae_load_genotypes)");
+    if (!gram) return set_err(e, -2, "pvae_pca_gram: gram is NULL");
+    if (scaler < PV_SCALE_CENTER || scaler > PV_SCALE_STANDARD) return set_err(e, -2, "pvae_pca_gram: scaler %d", scaler);
+    const int n = (int)e->n_samples, nt = (n + 127) / 128, n_pairs = nt * (nt + 1) / 2;
+    const int64_t row_words = e->row_bytes / 8;
+    // SNP-axis slices: enough workgroups to fill the chip a few times over, partials capped at 2 GiB
+    int n_slices = std::max(1, std::min(e->nblk, (2048 + n_pairs - 1) / n_pairs));
+    n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(n_slices, ((int64_t)2 << 30) / ((int64_t)n_pairs * 128 * 128 * 8)));
+    const int per = (e->nblk + n_slices - 1) / n_slices;
+    n_slices = (e->nblk + per - 1) / per;
+    std::vector<int2> pairs;
+    for (int i = 0; i < nt; ++i)
+        for (int j = i; j < nt; ++j) pairs.push_back(int2{i, j});
+    double2* sc = nullptr;
+    double *dmean = nullptr, *dstd = nullptr, *part = nullptr, *G = nullptr;
+    int2* dpairs = nullptr;
+    int* dbad = nullptr;
+    int rc = 0, bad = 0;
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc(&sc, (size_t)e->nblk * 32 * sizeof(double2)));
+        HIPCHK(hipMalloc(&dmean, (size_t)e->L * sizeof(double)));
+        HIPCHK(hipMalloc(&dstd, (size_t)e->L * sizeof(double)));
+        HIPCHK(hipMalloc(&part, (size_t)n_slices * n_pairs * 128 * 128 * sizeof(double)));
+        HIPCHK(hipMalloc(&G, (size_t)n * n * sizeof(double)));
+        HIPCHK(hipMalloc(&dpairs, pairs.size() * sizeof(int2)));
+        HIPCHK(hipMalloc(&dbad, sizeof(int)));
+        HIPCHK(hipMemsetAsync(dbad, 0, sizeof(int), e->stream));
+        HIPCHK(hipMemcpyAsync(dpairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(pvk_site_scale, dim3((e->nblk + 15) / 16), dim3(256), 0, e->stream, (const uint64_t*)e->geno, row_words, n,
+                           e->nblk, (int64_t)e->L, scaler, sc, dmean, dstd, dbad);
+        int r2;
+        if ((r2 = launch_check(e, "site_scale"))) return r2;
+        HIPCHK(hipMemcpyAsync(&bad, dbad, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (bad)
+            return set_err(e, -7, "pvae_pca_gram: %d site(s) have zero scale under this scaler (the reference divides by zero there)", bad);
+        hipLaunchKernelGGL(pvk_gram, dim3(n_pairs * n_slices), dim3(256), 0, e->stream, (const uint64_t*)e->geno, row_words, n, e->nblk,
+                           (const double2*)sc, (const int2*)dpairs, n_pairs, per, part);
+        if ((r2 = launch_check(e, "gram"))) return r2;
+        hipLaunchKernelGGL(pvk_gram_reduce, dim3(64, n_pairs), dim3(256), 0, e->stream, (const double*)part, (const int2*)dpairs, n_pairs,
+                           n_slices, n, G);
+        if ((r2 = launch_check(e, "gram_reduce"))) return r2;
+        HIPCHK(hipMemcpyAsync(gram, G, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        if (site_mean) HIPCHK(hipMemcpyAsync(site_mean, dmean, (size_t)e->L * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        if (site_std) HIPCHK(hipMemcpyAsync(site_std, dstd, (size_t)e->L * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return 0;
+    };
+    rc = body();
+    hipFree(sc); hipFree(dmean); hipFree(dstd); hipFree(part); hipFree(G); hipFree(dpairs); hipFree(dbad);
+    return rc;
 }
 
 int pvae_snapshot_best(pvae_engine* e) {

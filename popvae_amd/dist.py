@@ -162,6 +162,22 @@ class ShardedEngine:
             outs.append(self.eng.stage_encode(len(r)))
         return tuple(np.concatenate([o[k] for o in outs]) for k in range(3))
 
+    def pca_gram(self, scaler="patterson"):
+        """Global Gram matrix: the scaler is per site, so the ranks' local Gram matrices simply add up."""
+        G = self.eng.pca_gram(scaler)
+        if self.world > 1 or self.force_collectives:
+            t = self._torch.from_numpy(G)
+            dev = self._bufs[0].device if isinstance(self._bufs[0], self._torch.Tensor) else "cpu"
+            if str(dev) != "cpu":
+                t = t.to(dev)
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.pg)
+            G = t.cpu().numpy()
+        return G
+
+    def pca(self, scaler="Patterson", n_components=20):
+        from .pca import coords_from_gram
+        return coords_from_gram(self.pca_gram(scaler), n_components)
+
     def train_epoch(self, perm, val_rows, eps_fn=None):
         """One epoch of fit (K8/K9): batches of batch_size, short last batch kept; plain batch means."""
         B = self.batch_size

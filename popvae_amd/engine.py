@@ -19,7 +19,7 @@ ENGINE_SYMBOLS = [
     "pvae_synchronize", "pvae_load_genotypes", "pvae_num_tensors", "pvae_tensor_shape", "pvae_set_tensor",
     "pvae_get_tensor", "pvae_init_weights", "pvae_get_moment", "pvae_reset_optimizer", "pvae_set_lr", "pvae_get_lr",
     "pvae_train_step", "pvae_eval_step", "pvae_grad_step", "pvae_get_grad", "pvae_train_epoch", "pvae_encode",
-    "pvae_decode", "pvae_snapshot_best", "pvae_restore_best", "pvae_exchange_buffer", "pvae_stage_a", "pvae_stage_b",
+    "pvae_decode", "pvae_pca_gram", "pvae_snapshot_best", "pvae_restore_best", "pvae_exchange_buffer", "pvae_stage_a", "pvae_stage_b",
     "pvae_stage_c", "pvae_stage_encode", "pvae_set_timing", "pvae_get_timing",
 ]
 
@@ -71,6 +71,8 @@ def lib():
         L.pvae_train_epoch.argtypes = [vp, _i32p, i32, _i32p, i32, _fopt, _fopt]
         L.pvae_encode.argtypes = [vp, _i32p, i32, _fopt, _fopt, _fopt, _fopt]
         L.pvae_decode.argtypes = [vp, _f32p, i32, _f32p]
+        _dopt = C.POINTER(C.c_double)
+        L.pvae_pca_gram.argtypes = [vp, C.c_int, _dopt, _dopt, _dopt]
         L.pvae_snapshot_best.argtypes = [vp]
         L.pvae_restore_best.argtypes = [vp]
         L.pvae_exchange_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(i64)]
@@ -239,6 +241,23 @@ class Engine:
         out = np.empty((z.shape[0], self.n_snps), np.float32)
         self._ck(lib().pvae_decode(self._h, z.reshape(-1), z.shape[0], out.reshape(-1)))
         return out
+
+    def pca_gram(self, scaler="patterson", want_sites=False):
+        """Gram matrix (float64 [N, N]) of the per-site scaled genotype matrix of ALL loaded samples, for
+        popvae_amd.pca (popvae.py:528-533).  scaler: "patterson" | "standard" | anything else = centre only
+        (allel.stats.decomposition.get_scaler).  want_sites: also return the per-site (mean, std)."""
+        code = {"patterson": 1, "standard": 2}.get(scaler.lower() if isinstance(scaler, str) else None, 0)
+        n = getattr(self, "n_samples", 0)
+        if not n:
+            raise RuntimeError("no genotypes loaded")
+        G = np.empty((n, n), np.float64)
+        dp = C.POINTER(C.c_double)
+        mean = std = None
+        if want_sites:
+            mean, std = np.empty(self.n_snps, np.float64), np.empty(self.n_snps, np.float64)
+        self._ck(lib().pvae_pca_gram(self._h, code, G.ctypes.data_as(dp), mean.ctypes.data_as(dp) if want_sites else None,
+                                     std.ctypes.data_as(dp) if want_sites else None))
+        return (G, mean, std) if want_sites else G
 
     def snapshot_best(self):
         self._ck(lib().pvae_snapshot_best(self._h))

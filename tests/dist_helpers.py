@@ -61,6 +61,10 @@ class OracleShardEngine:
     def close(self):
         pass
 
+    def pca_gram(self, scaler="patterson"):
+        xs = O.pca_scale(self.dc.T, scaler)[0]
+        return xs.T @ xs
+
     # -- the three stages ------------------------------------------------------------------------
     def stage_a(self, rows, eps, mode):
         self.n = len(rows)
@@ -152,6 +156,7 @@ def make_problem(N=40, L=333, W=32, D=3, K=2, seed=7):
     g = np.random.default_rng(seed)
     f = np.clip(g.beta(0.5, 0.5, L), 0.02, 0.98)
     dc = g.binomial(2, f, size=(N, L)) * 0.5
+    dc[0, :] = 0.5   # no monomorphic site (the Patterson scaler divides by zero there, in the reference too)
     w = O.init_weights(L, W, D, K, seed=seed, dtype=np.float64)
     for t in w:
         if t.ndim == 1:
@@ -202,6 +207,8 @@ def sharded_worker(rank, world, port, out_path, use_gpu, dims):
     res["encode"] = sh.encode(rows, eps)
     res["eval"] = sh.eval_step(rows[:17], eps[:17])[0]
     res["weights"] = sh.get_weights_shard()
+    if dims[0] > 8:
+        res["pca"] = sh.pca("Patterson", 6)[0]
     np.save(out_path + f".{rank}.npy", np.array([res], dtype=object), allow_pickle=True)
     sh.close()
     dist.barrier()
@@ -231,6 +238,8 @@ def reference_run(dims):
     out["encode"] = O.encode(w, dc, eps, D, K)
     out["eval"] = O.forward(w, dc[:17], eps[:17], D, K)["loss"]
     out["weights"] = w
+    dc2 = dc.copy()
+    out["pca"] = O.pca(dc2, "Patterson", 6)[0] if N > 8 else None
     return out
 
 
@@ -241,6 +250,9 @@ def compare(res_by_rank, ref, dims, rtol, wtol):
         assert abs(res["grad_loss"] - ref["grad_loss"]) <= rtol * abs(ref["grad_loss"])
         np.testing.assert_allclose(res["losses"], ref["losses"], rtol=rtol)
         assert abs(res["eval"] - ref["eval"]) <= rtol * abs(ref["eval"])
+        if ref.get("pca") is not None:
+            sgn = np.sign(np.sum(res["pca"] * ref["pca"], axis=0))
+            assert np.abs(res["pca"] * sgn - ref["pca"]).max() <= 1e-8 * np.abs(ref["pca"]).max()
         for a, b in zip(res["encode"], ref["encode"]):
             assert np.abs(a - b).max() <= 10 * rtol * max(1.0, np.abs(b).max())
 

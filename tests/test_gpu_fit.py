@@ -103,7 +103,7 @@ def test_cli_end_to_end(tmp_path, monkeypatch):
     monkeypatch.delenv("RANK", raising=False)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     rc = cli.main(["--infile", vcf, "--out", out, "--seed", "42", "--max_epochs", "40", "--patience", "10",
-                   "--width", "64", "--depth", "3", "--save_weights"])
+                   "--width", "64", "--depth", "3", "--save_weights", "--PCA", "--n_pc_axes", "5"])
     assert rc == 0
     # the integer path is bit-exact: same kept sites / imputed matrix / split as numpy's legacy stream gives
     rs = np.random.RandomState(42)
@@ -126,6 +126,15 @@ def test_cli_end_to_end(tmp_path, monkeypatch):
     if os.path.exists(out + "_weights.npz"):
         wz = np.load(out + "_weights.npz")
         assert wz["enc_dense0__kernel"].shape == (dc_o.shape[1], 64)
+    # --PCA (popvae.py:528-540, 561-563): same coordinates as the oracle's allel.pca restatement on the imputed matrix
+    pc = [x.split("\t") for x in open(out + "_pca.txt").read().splitlines()]
+    assert pc[0] == ["PC1", "PC2", "PC3", "PC4", "PC5", "sampleID"] and [r[5] for r in pc[1:]] == samples
+    got = np.array([[float(v) for v in r[:5]] for r in pc[1:]])
+    want = O.pca(dc_o, "Patterson", 5)[0]
+    sgn = np.sign(np.sum(got * want, axis=0))
+    assert np.abs(got * sgn - want).max() <= 1e-8 * np.abs(want).max()
+    rt = np.loadtxt(out + "_runtimes.txt")
+    assert rt.shape == (2,) and (rt > 0).all()
 
 
 def test_cli_grid_search_small(tmp_path, monkeypatch):
