@@ -53,8 +53,8 @@ struct TensorRef {
     int64_t rows, cols;  // Keras shape (cols = 0 for bias)
 };
 
-enum Cat { C_GATHER, C_ENC_FWD, C_NARROW_FWD, C_DEC, C_NARROW_BWD, C_ENC_BWD, C_APPLY, C_NCAT };
-const char* kCatNames[C_NCAT] = {"gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd", "apply"};
+enum Cat { C_GATHER, C_ENC_FWD, C_NARROW_FWD, C_DEC, C_NARROW_BWD, C_ENC_BWD, C_NCAT };
+const char* kCatNames[C_NCAT] = {"gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd"};
 
 }  // namespace
 
@@ -265,14 +265,17 @@ int setup_kernel_attrs(pvae_engine* e) {
     HIPCHK(allow_lds(pvk_narrow_fwd, pvn_lds_fwd()));
     HIPCHK(allow_lds(pvk_narrow_bwd<PV_MODE_TRAIN>, pvn_lds_bwd()));
     HIPCHK(allow_lds(pvk_narrow_bwd<PV_MODE_GRAD>, pvn_lds_bwd()));
+    HIPCHK(allow_lds(pvk_narrow_bwd<PV_MODE_TRAIN_ACC>, pvn_lds_bwd()));
 #define PV_ATTR(N)                                                                    \
     HIPCHK(allow_lds(pvk_enc_fwd<N>, lds_enc_fwd(N)));                                \
     HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_TRAIN>, lds_dec(N)));                      \
     HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_GRAD>, lds_dec(N)));                       \
+    HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_TRAIN_ACC>, lds_dec(N)));                  \
     HIPCHK(allow_lds(pvk_dec<N, 0, PV_MODE_TRAIN>, lds_dec(N)));                      \
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN, 0>), lds_enc_bwd(e->Wp)));        \
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN, 1>), lds_enc_bwd_fused(N, e->Wp)));  \
-    HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_GRAD, 0>), lds_enc_bwd(e->Wp)));
+    HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_GRAD, 0>), lds_enc_bwd(e->Wp)));         \
+    HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN_ACC, 0>), lds_enc_bwd(e->Wp)));
     switch (e->NWB) {
         case 1: PV_ATTR(1) break;
         case 2: PV_ATTR(2) break;
@@ -283,6 +286,7 @@ int setup_kernel_attrs(pvae_engine* e) {
 #define PV_ATTR_G(G)                                                                  \
     HIPCHK(allow_lds(pvk_dec_grp<G, 1, PV_MODE_TRAIN>, lds_dec_grp(G)));              \
     HIPCHK(allow_lds(pvk_dec_grp<G, 1, PV_MODE_GRAD>, lds_dec_grp(G)));               \
+    HIPCHK(allow_lds(pvk_dec_grp<G, 1, PV_MODE_TRAIN_ACC>, lds_dec_grp(G)));          \
     HIPCHK(allow_lds(pvk_dec_grp<G, 0, PV_MODE_TRAIN>, lds_dec_grp(G)));
     if (e->ngrp == 2) { PV_ATTR_G(2) }
     if (e->ngrp == 4) { PV_ATTR_G(4) }
@@ -361,6 +365,7 @@ int build_bwd_ops(pvae_engine* e, bool grad, PvBwdOp** out) {
         o.dpre = e->dpre_bufs[nd++];
         o.W = d.W.w; o.mW = grad ? d.W.g : d.W.m; o.vW = grad ? nullptr : d.W.v;
         o.B = d.B.w; o.mB = grad ? d.B.g : d.B.m; o.vB = grad ? nullptr : d.B.v;
+        o.gW = d.W.g; o.gB = d.B.g;
         o.in = in; o.Y = Y; o.kin = d.kin; o.nout = d.nout; o.act = d.act; o.kind = PVN_DENSE;
         ops.push_back(o);
     };
@@ -374,6 +379,7 @@ int build_bwd_ops(pvae_engine* e, bool grad, PvBwdOp** out) {
     for (int i = D - 2; i >= 0; --i) dense(e->enc[i], e->h[i], e->h[i + 1]);
     PvBwdOp f{};
     f.kind = PVN_FIRST_BIAS; f.dpre = e->dpre1; f.B = e->b1.w; f.mB = grad ? e->b1.g : e->b1.m; f.vB = grad ? nullptr : e->b1.v;
+    f.gB = e->b1.g;
     f.Y = e->h[0]; f.nout = e->Wp; f.kin = 0; f.act = PV_ACT_ELU;
     ops.push_back(f);
     e->n_bwd_ops = (int)ops.size();
@@ -451,46 +457,40 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
             if ((rc = allocf(e, &e->Vout.g, e->Vout.n))) return rc;
             if ((rc = allocf(e, &e->cout.g, e->cout.n))) return rc;
         }
-        if (e->ngrp > 1) {
-#define PV_DEC_G(G, TR, MD, V_, M_, VV_, V2_, M2_, VV2_, C_, MC_, VC_)                                                    \
-    hipLaunchKernelGGL((pvk_dec_grp<G, TR, MD>), dim3(e->dec_wgs), dim3(512), lds_dec_grp(G), e->stream, V_, M_, VV_, V2_, M2_, \
-                       VV2_, C_, MC_, VC_, gD, e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4)
-#define PV_DEC_GG(TR, MD, ...)                                  \
-    do {                                                        \
-        if (e->ngrp == 2) PV_DEC_G(2, TR, MD, __VA_ARGS__);     \
-        else PV_DEC_G(4, TR, MD, __VA_ARGS__);                  \
+        // TRAIN / TRAIN_ACC stream copy -> copy and swap; GRAD dumps into the g buffers; eval only reads V and c
+        float* nul = nullptr;
+        const bool upd = mode == 0 || mode == 4;
+        const float *aV = e->Vout.w, *amV = upd ? e->Vout.m : nul, *avV = upd ? e->Vout.v : nul;
+        float *aV2 = upd ? e->Vout.w2 : nul, *amV2 = upd ? e->Vout.m2 : (mode == 2 ? e->Vout.g : nul), *avV2 = upd ? e->Vout.v2 : nul;
+        float *acb = e->cout.w, *amC = upd ? e->cout.m : (mode == 2 ? e->cout.g : nul), *avC = upd ? e->cout.v : nul;
+        const float *agV = mode == 4 ? e->Vout.g : nul, *agC = mode == 4 ? e->cout.g : nul;
+        if (mode == 4 && (!agV || !agC)) return set_err(e, -6, "train-with-accumulated-gradients step without a gradient dump");
+#define PV_DEC_LAUNCH(KERN, THREADS, LDS)                                                                                      \
+    hipLaunchKernelGGL(KERN, dim3(e->dec_wgs), dim3(THREADS), LDS, e->stream, aV, amV, avV, aV2, amV2, avV2, acb, amC, avC, gD, \
+                       e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4, agV, agC)
+#define PV_DEC_MODES(K3, THREADS, LDS)                                                     \
+    do {                                                                                   \
+        if (mode == 0) PV_DEC_LAUNCH((K3(1, PV_MODE_TRAIN)), THREADS, LDS);                \
+        else if (mode == 2) PV_DEC_LAUNCH((K3(1, PV_MODE_GRAD)), THREADS, LDS);            \
+        else if (mode == 4) PV_DEC_LAUNCH((K3(1, PV_MODE_TRAIN_ACC)), THREADS, LDS);       \
+        else PV_DEC_LAUNCH((K3(0, PV_MODE_TRAIN)), THREADS, LDS);                          \
     } while (0)
-            float* nul = nullptr;
-            if (mode == 0) {
-                PV_DEC_GG(1, PV_MODE_TRAIN, e->Vout.w, e->Vout.m, e->Vout.v, e->Vout.w2, e->Vout.m2, e->Vout.v2, e->cout.w,
-                          e->cout.m, e->cout.v);
-                e->Vout.swap();
-            } else if (mode == 2) {
-                PV_DEC_GG(1, PV_MODE_GRAD, e->Vout.w, nul, nul, nul, e->Vout.g, nul, e->cout.w, e->cout.g, nul);
-            } else {
-                PV_DEC_GG(0, PV_MODE_TRAIN, e->Vout.w, nul, nul, nul, nul, nul, e->cout.w, nul, nul);
-            }
-#undef PV_DEC_GG
-#undef PV_DEC_G
-        } else
-        if (mode == 0) {
-            PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 1, PV_MODE_TRAIN>), dim3(e->dec_wgs), dim3(256), lds_dec(N_),
-                                                  e->stream, e->Vout.w, e->Vout.m, e->Vout.v, e->Vout.w2, e->Vout.m2,
-                                                  e->Vout.v2, e->cout.w, e->cout.m, e->cout.v, gD, e->Xt, e->nblk,
-                                                  (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4));
-            e->Vout.swap();
-        } else if (mode == 2) {
-            PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 1, PV_MODE_GRAD>), dim3(e->dec_wgs), dim3(256), lds_dec(N_),
-                                                  e->stream, e->Vout.w, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                                                  e->Vout.g, (float*)nullptr, e->cout.w, e->cout.g, (float*)nullptr, gD,
-                                                  e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4));
+        if (e->ngrp == 2) {
+#define PV_K3(TR, MD) pvk_dec_grp<2, TR, MD>
+            PV_DEC_MODES(PV_K3, 512, lds_dec_grp(2));
+#undef PV_K3
+        } else if (e->ngrp == 4) {
+#define PV_K3(TR, MD) pvk_dec_grp<4, TR, MD>
+            PV_DEC_MODES(PV_K3, 512, lds_dec_grp(4));
+#undef PV_K3
         } else {
-            PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 0, PV_MODE_TRAIN>), dim3(e->dec_wgs), dim3(256), lds_dec(N_),
-                                                  e->stream, e->Vout.w, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                                                  (float*)nullptr, (float*)nullptr, e->cout.w, (float*)nullptr,
-                                                  (float*)nullptr, gD, e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart,
-                                                  e->losspart, e->ts4));
+#define PV_K3(TR, MD) pvk_dec<N_, TR, MD>
+            PV_DISPATCH_NWB(e, PV_DEC_MODES(PV_K3, 256, lds_dec(N_)));
+#undef PV_K3
         }
+#undef PV_DEC_MODES
+#undef PV_DEC_LAUNCH
+        if (upd) e->Vout.swap();
         if ((rc = launch_check(e, "dec"))) return rc;
         const int n_dg = mode == 1 ? 0 : 32 * e->Wp;
         // eval: only the recon sums are produced (they live behind the dg block of the exchange buffer)
@@ -507,73 +507,82 @@ int enc_bwd_launch(pvae_engine* e, int km, bool fuse = false, int next_off = 0, 
     const uint8_t* nog = nullptr;
     const int* nor = nullptr;
     float* nof = nullptr;
+    const float* nogw = nullptr;
     if (km == PV_MODE_GRAD) {
         if (!e->W1.g && (rc = allocf(e, &e->W1.g, e->W1.n))) return rc;
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_GRAD, 0>), dim3(e->encb_wgs), dim3(256),
                                               lds_enc_bwd(e->Wp), e->stream, e->W1.w, (float*)nullptr, (float*)nullptr,
                                               (float*)nullptr, e->W1.g, (float*)nullptr, e->dpre1, e->Wp, e->Xt, e->nblk,
-                                              e->ngrp, e->st, e->adam, nog, (int64_t)0, nor, 0, 0, nof, e->ts4));
+                                              e->ngrp, e->st, e->adam, nog, (int64_t)0, nor, 0, 0, nof, e->ts4, nogw));
+    } else if (km == PV_MODE_TRAIN_ACC) {
+        if (!e->W1.g) return set_err(e, -6, "train-with-accumulated-gradients step without a gradient dump");
+        PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN_ACC, 0>), dim3(e->encb_wgs), dim3(256),
+                                              lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
+                                              e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam, nog,
+                                              (int64_t)0, nor, 0, 0, nof, e->ts4, (const float*)e->W1.g));
+        e->W1.swap();
     } else if (fuse) {
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 1>), dim3(e->encb_wgs), dim3(256),
                                               lds_enc_bwd_fused(N_, e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
                                               e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam,
                                               (const uint8_t*)e->geno, e->row_bytes, (const int*)e->d_rows, next_off, next_n,
-                                              e->encpart, e->ts4));
+                                              e->encpart, e->ts4, nogw));
         e->W1.swap();
     } else {
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 0>), dim3(e->encb_wgs), dim3(256),
                                               lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
                                               e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam, nog,
-                                              (int64_t)0, nor, 0, 0, nof, e->ts4));
+                                              (int64_t)0, nor, 0, 0, nof, e->ts4, nogw));
         e->W1.swap();
     }
     return launch_check(e, "enc_bwd");
 }
 
-// stage C: loss, narrow backward (+Adam), wide encoder backward (+Adam)
+int ensure_grad_bufs(pvae_engine* e) {
+    int rc = 0;
+    HIPCHK(hipStreamSynchronize(e->stream));  // the op tables are rewritten below
+    for_each_buf(e, [&](Buf3& b) { if (!rc && !b.g) rc = allocf(e, &b.g, b.n); });
+    if (rc) return rc;
+    // both op tables carry the g pointers (TRAIN_ACC reads them through the train table)
+    if ((rc = build_bwd_ops(e, false, &e->d_bwd_ops))) return rc;
+    return build_bwd_ops(e, true, &e->d_bwd_ops_grad);
+}
+
+// stage C: loss, narrow backward (+Adam), wide encoder backward (+Adam).  mode: 0 train, 1 eval, 2 gradient dump,
+// 4 train on (this pass + dumped gradients)
 int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next_off = 0, int next_n = 0) {
     int rc;
+    const int km = mode == 2 ? PV_MODE_GRAD : mode == 4 ? PV_MODE_TRAIN_ACC : PV_MODE_TRAIN;
+    if ((mode == 2 || mode == 4) && !e->d_bwd_ops_grad && (rc = ensure_grad_bufs(e))) return rc;
+    const PvBwdOp* table = km == PV_MODE_GRAD ? e->d_bwd_ops_grad : e->d_bwd_ops;
     if (e->fused_narrow) {
         {
         Timer t(e, C_NARROW_BWD);
-        if (mode == 2) {
-            if (!e->d_bwd_ops_grad) {
-                int rc2 = 0;
-                for_each_buf(e, [&](Buf3& b) { if (!rc2 && !b.g) rc2 = allocf(e, &b.g, b.n); });
-                if (rc2) return rc2;
-                if ((rc = build_bwd_ops(e, true, &e->d_bwd_ops_grad))) return rc;
-            }
-            hipLaunchKernelGGL(pvk_narrow_bwd<PV_MODE_GRAD>, dim3(e->narrow_warm ? 8 * (e->n_bwd_ops + 1) : 1), dim3(PVN_THREADS), pvn_lds_bwd(), e->stream,
-                               e->d_bwd_ops_grad, e->n_bwd_ops, e->xch1, e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st,
-                               e->adam, d_out3, 1);
-            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_GRAD>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, e->d_bwd_ops_grad,
-                               e->st, e->adam);
-        } else {
-            hipLaunchKernelGGL(pvk_narrow_bwd<PV_MODE_TRAIN>, dim3(e->narrow_warm && mode == 0 ? 8 * (e->n_bwd_ops + 1) : 1), dim3(PVN_THREADS), pvn_lds_bwd(), e->stream,
-                               e->d_bwd_ops, e->n_bwd_ops, e->xch1, e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st,
-                               e->adam, d_out3, mode == 0 ? 1 : 0);
-            if (mode == 0)
-                hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, e->d_bwd_ops,
-                                   e->st, e->adam);
-        }
+        const dim3 chain_grid(e->narrow_warm && mode != 1 ? 8 * (e->n_bwd_ops + 1) : 1);
+#define PV_NARROW_BWD(MD)                                                                                                      \
+    hipLaunchKernelGGL(pvk_narrow_bwd<MD>, chain_grid, dim3(PVN_THREADS), pvn_lds_bwd(), e->stream, table, e->n_bwd_ops, e->xch1, \
+                       e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st, e->adam, d_out3, mode == 1 ? 0 : 1)
+        if (km == PV_MODE_GRAD) PV_NARROW_BWD(PV_MODE_GRAD);
+        else if (km == PV_MODE_TRAIN_ACC) PV_NARROW_BWD(PV_MODE_TRAIN_ACC);
+        else PV_NARROW_BWD(PV_MODE_TRAIN);
+#undef PV_NARROW_BWD
+        if (km == PV_MODE_GRAD)
+            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_GRAD>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam);
+        else if (km == PV_MODE_TRAIN_ACC)
+            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN_ACC>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam);
+        else if (mode == 0)
+            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam);
         if ((rc = launch_check(e, "narrow_bwd"))) return rc;
         }
         if (mode == 1) return 0;
-        return enc_bwd_launch(e, mode == 2 ? PV_MODE_GRAD : PV_MODE_TRAIN, fuse, next_off, next_n);
+        return enc_bwd_launch(e, km, fuse, next_off, next_n);
     }
     hipLaunchKernelGGL(pvk_loss_final, dim3(1), dim3(64), 0, e->stream, e->xch1 + 32 * e->Wp, e->kl, e->st, d_out3);
     if ((rc = launch_check(e, "loss_final"))) return rc;
     if (mode == 1) return 0;
-    const int km = mode == 2 ? PV_MODE_GRAD : PV_MODE_TRAIN;
     {
         Timer t(e, C_NARROW_BWD);
         const int D = e->D;
-        if (km == PV_MODE_GRAD && !e->d_bwd_ops_grad) {
-            int rc2 = 0;
-            for_each_buf(e, [&](Buf3& b) { if (!rc2 && !b.g) rc2 = allocf(e, &b.g, b.n); });
-            if (rc2) return rc2;
-            if ((rc = build_bwd_ops(e, true, &e->d_bwd_ops_grad))) return rc;
-        }
         // the chain: per layer dpre (kept in dpre_bufs, in op-table order) and dIn; dY ping-pongs between xch1/dA/dB
         const float* dY = e->xch1;
         float* bufs[2] = {e->dA, e->dB};
@@ -597,24 +606,23 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
             pp ^= 1;
         }
         // weight / bias gradients + Adam of all narrow layers: one launch, one wave per 32x32 block
-        const int maxb = (e->Wp / 32) * (e->Wp / 32);
-        if (km == PV_MODE_GRAD)
-            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_GRAD>, dim3(maxb, e->n_bwd_ops), dim3(64), 0, e->stream, e->d_bwd_ops_grad,
-                               e->st, e->adam);
-        else
-            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN>, dim3(maxb, e->n_bwd_ops), dim3(64), 0, e->stream, e->d_bwd_ops,
-                               e->st, e->adam);
-        if ((rc = launch_check(e, "narrow_adam"))) return rc;
-        // first (wide) layer: dpre1 + b1
+        const dim3 agrid((e->Wp / 32) * (e->Wp / 32), e->n_bwd_ops);
+        const dim3 bgrid((e->Wp + 63) / 64);
+        // first (wide) layer's bias rides on the dpre1 kernel
         if (km == PV_MODE_GRAD) {
-            if (!e->b1.g && (rc = allocf(e, &e->b1.g, e->b1.n))) return rc;
-            hipLaunchKernelGGL(pvk_bias_bwd<PV_MODE_GRAD>, dim3((e->Wp + 63) / 64), dim3(64), 0, e->stream, e->h[0], dY,
-                               e->Wp, (int)PV_ACT_ELU, e->dpre1, e->b1.w, e->b1.g, (float*)nullptr, e->st, e->adam);
+            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_GRAD>, agrid, dim3(64), 0, e->stream, table, e->st, e->adam);
+            hipLaunchKernelGGL(pvk_bias_bwd<PV_MODE_GRAD>, bgrid, dim3(64), 0, e->stream, e->h[0], dY, e->Wp, (int)PV_ACT_ELU, e->dpre1,
+                               e->b1.w, e->b1.g, (float*)nullptr, e->st, e->adam, (const float*)nullptr);
+        } else if (km == PV_MODE_TRAIN_ACC) {
+            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN_ACC>, agrid, dim3(64), 0, e->stream, table, e->st, e->adam);
+            hipLaunchKernelGGL(pvk_bias_bwd<PV_MODE_TRAIN_ACC>, bgrid, dim3(64), 0, e->stream, e->h[0], dY, e->Wp, (int)PV_ACT_ELU,
+                               e->dpre1, e->b1.w, e->b1.m, e->b1.v, e->st, e->adam, (const float*)e->b1.g);
         } else {
-            hipLaunchKernelGGL(pvk_bias_bwd<PV_MODE_TRAIN>, dim3((e->Wp + 63) / 64), dim3(64), 0, e->stream, e->h[0], dY,
-                               e->Wp, (int)PV_ACT_ELU, e->dpre1, e->b1.w, e->b1.m, e->b1.v, e->st, e->adam);
+            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN>, agrid, dim3(64), 0, e->stream, table, e->st, e->adam);
+            hipLaunchKernelGGL(pvk_bias_bwd<PV_MODE_TRAIN>, bgrid, dim3(64), 0, e->stream, e->h[0], dY, e->Wp, (int)PV_ACT_ELU, e->dpre1,
+                               e->b1.w, e->b1.m, e->b1.v, e->st, e->adam, (const float*)nullptr);
         }
-        if ((rc = launch_check(e, "bias_bwd"))) return rc;
+        if ((rc = launch_check(e, "narrow_adam/bias_bwd"))) return rc;
     }
     return enc_bwd_launch(e, km, fuse, next_off, next_n);
 }
@@ -685,36 +693,18 @@ int fetch_out3(pvae_engine* e, float* out3) {
     return 0;
 }
 
-// Adam from the accumulated gradient buffers (batches above 32 rows): wide tensors stream copy -> copy like a
-// train step does, the narrow ones update in place
-int apply_gradients(pvae_engine* e) {
-    Timer t(e, C_APPLY);
-    int rc = 0;
-    for_each_buf(e, [&](Buf3& b) {
-        if (rc) return;
-        if (!b.g) { rc = set_err(e, -6, "apply_gradients: no gradient buffer"); return; }
-        if (b.il_tile) {
-            hipLaunchKernelGGL(pvk_apply_wide, dim3(2048), dim3(256), 0, e->stream, (const f32x4*)b.w, (f32x4*)b.w2,
-                               (const f32x4*)b.g, b.n / b.il_tile, (int)(b.il_tile / 4), e->st, e->adam);
-            b.swap();
-        } else {
-            hipLaunchKernelGGL(pvk_apply_lin, dim3((unsigned)std::min<int64_t>((b.n + 255) / 256, 1024)), dim3(256), 0, e->stream, b.w,
-                               b.m, b.v, b.g, b.n, e->st, e->adam);
-        }
-    });
-    return rc ? rc : launch_check(e, "apply_gradients");
-}
-
 // one 32-row tile of a larger batch (rows already on the device at d_rows[row_offset..]): forward, loss part,
-// gradients stored (first tile) or added (later tiles); inv_b is 1 / (rows of the WHOLE batch), so that the
-// tiles' loss parts and gradients add up to the batch mean
-int run_tile(pvae_engine* e, int row_offset, int nrows, int n_batch, int tile, bool eval, float* d_out3) {
+// gradients stored (first tile) or added (later tiles) in the g buffers; the LAST tile of a train step runs the
+// training kernels, which add the dumped gradients to their own before Adam (PV_MODE_TRAIN_ACC) -- every wide
+// weight / moment byte is still touched once per batch.  inv_b is 1 / (rows of the WHOLE batch), so that the
+// tiles' loss parts and gradients add up to the batch mean.  mode: 1 eval, 2 gradient dump, 4 last tile of a train step
+int run_tile(pvae_engine* e, int row_offset, int nrows, int n_batch, int tile, int mode, float* d_out3) {
     int rc;
     hipLaunchKernelGGL(pvk_tile_begin, dim3(1), dim3(64), 0, e->stream, e->st, nrows, 1.f / (float)n_batch, tile > 0 ? 1 : 0);
     if ((rc = launch_check(e, "tile_begin"))) return rc;
     if ((rc = stage_a(e, row_offset, true))) return rc;
-    if ((rc = stage_b(e, eval ? 1 : 2))) return rc;
-    return stage_c(e, eval ? 1 : 2, d_out3);
+    if ((rc = stage_b(e, mode))) return rc;
+    return stage_c(e, mode, d_out3);
 }
 
 int full_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3, int mode) {
@@ -736,9 +726,9 @@ int full_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, 
         const int nb = std::min(32, n - 32 * t);
         // begin_batch uploads this tile's rows (+ eps) and, on the first tile of a train step, advances Adam's t
         if ((rc = begin_batch(e, rows + 32 * t, nb, eps ? eps + (size_t)32 * t * e->K : nullptr, mode == 0 && t == 0))) return rc;
-        if ((rc = run_tile(e, 0, nb, n, t, mode == 1, e->d_loss + 3 * t))) return rc;
+        const int tm = mode == 1 ? 1 : (mode == 0 && t == nt - 1) ? 4 : 2;
+        if ((rc = run_tile(e, 0, nb, n, t, tm, e->d_loss + 3 * t))) return rc;
     }
-    if (mode == 0 && (rc = apply_gradients(e))) return rc;
     std::vector<float> hl((size_t)nt * 3);
     HIPCHK(hipMemcpyAsync(hl.data(), e->d_loss, hl.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1159,9 +1149,9 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
             for (int t = 0; t * 32 < nb; ++t) {
                 hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, 32 * e->K, e->cfg.seed, e->d_counter);
                 if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
-                if ((rc = run_tile(e, base + s * B + 32 * t, std::min(32, nb - 32 * t), nb, t, phase == 1, slot + 3 * t))) return rc;
+                const int tm = phase == 1 ? 1 : (t + 1) * 32 >= nb ? 4 : 2;
+                if ((rc = run_tile(e, base + s * B + 32 * t, std::min(32, nb - 32 * t), nb, t, tm, slot + 3 * t))) return rc;
             }
-            if (phase == 0 && (rc = apply_gradients(e))) return rc;
         }
     }
     for (int phase = 0; phase < 2 && tp == 1; ++phase) {

@@ -32,7 +32,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PV_ROW(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))
 
 enum { PV_ACT_LINEAR = 0, PV_ACT_ELU = 1 };
-enum { PV_MODE_TRAIN = 0, PV_MODE_GRAD = 1 };
+// TRAIN: Adam in the pass.  GRAD: gradient dump (PvStep.acc: store / add).  TRAIN_ACC: Adam on (this pass's gradient +
+// the dump of the earlier tiles) -- the last 32-row tile of a batch above 32 rows.
+enum { PV_MODE_TRAIN = 0, PV_MODE_GRAD = 1, PV_MODE_TRAIN_ACC = 2 };
 
 struct PvStep {  // device-resident per-step scalars (graph-replay friendly)
     int t;        // Adam iteration (1-based after pvk_step_begin)
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void pvk_dense_bwd(int K, const float* __restr
 template <int MODE>
 __global__ void pvk_bias_bwd(const float* __restrict__ Y, const float* __restrict__ dY, int N, int act,
                              float* __restrict__ dpre, float* __restrict__ bias, float* __restrict__ mB,
-                             float* __restrict__ vB, const PvStep* st, PvAdam adam) {
+                             float* __restrict__ vB, const PvStep* st, PvAdam adam, const float* __restrict__ gB) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const int nrows = st->nrows;
@@ -380,6 +382,7 @@ __global__ void pvk_bias_bwd(const float* __restrict__ Y, const float* __restric
         mB[n] = st->acc ? mB[n] + g : g;
     } else {
         float w = bias[n], m = mB[n], v = vB[n];
+        if (MODE == PV_MODE_TRAIN_ACC) g += gB[n];
         pv_adam(w, m, v, g, st->alpha, adam);
         bias[n] = w;
         mB[n] = m;
@@ -441,7 +444,8 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
                                                   float* __restrict__ cb, float* __restrict__ mC, float* __restrict__ vC,
                                                   const float* __restrict__ g, const uint64_t* __restrict__ Xt,
                                                   int nblk, int L, const PvStep* st, PvAdam adam,
-                                                  float* __restrict__ dgpart, float* __restrict__ losspart, int ts) {
+                                                  float* __restrict__ dgpart, float* __restrict__ losspart, int ts,
+                                                  const float* __restrict__ gV, const float* __restrict__ gC) {
     constexpr int WP = NWB * 32;
     constexpr int LDG = WP + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -524,6 +528,7 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
                     mC[l] = acc_grads ? mC[l] + dbias : dbias;
                 } else {
                     float w_ = bias, m_ = mC[l], v_ = vC[l];
+                    if (MODE == PV_MODE_TRAIN_ACC) dbias += gC[l];
                     pv_adam(w_, m_, v_, dbias, alpha, adam);
                     cb[l] = w_;
                     mC[l] = m_;
@@ -571,14 +576,16 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
                     const int off = (w * 4 + q) * 64 + lane;
                     if (MODE == PV_MODE_GRAD) {
                         f32x4 gq = {dv[q * 4 + 0], dv[q * 4 + 1], dv[q * 4 + 2], dv[q * 4 + 3]};
-                        if (acc_grads) gq += dM2[off];
-                        dM2[off] = gq;
+                        if (acc_grads) gq += __builtin_nontemporal_load(dM2 + off);
+                        __builtin_nontemporal_store(gq, dM2 + off);
                     } else {
                         f32x4 wq = vv[w][q], mq = __builtin_nontemporal_load(tM + off), vq = __builtin_nontemporal_load(tVv + off);
+                        f32x4 ga = {0.f, 0.f, 0.f, 0.f};
+                        if (MODE == PV_MODE_TRAIN_ACC) ga = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gV) + gbase + off);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float w_ = wq[e], m_ = mq[e], v_ = vq[e];
-                            pv_adam(w_, m_, v_, dv[q * 4 + e], alpha, adam);
+                            pv_adam(w_, m_, v_, MODE == PV_MODE_TRAIN_ACC ? dv[q * 4 + e] + ga[e] : dv[q * 4 + e], alpha, adam);
                             wq[e] = w_;
                             mq[e] = m_;
                             vq[e] = v_;
@@ -636,7 +643,8 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
                                                    float* __restrict__ cb, float* __restrict__ mC, float* __restrict__ vC,
                                                    const float* __restrict__ g, const uint64_t* __restrict__ Xt,
                                                    int nblk, int L, const PvStep* st, PvAdam adam,
-                                                   float* __restrict__ dgpart, float* __restrict__ losspart, int ts) {
+                                                   float* __restrict__ dgpart, float* __restrict__ losspart, int ts,
+                                                   const float* __restrict__ gV, const float* __restrict__ gC) {
     constexpr int NWB = 4;
     constexpr int WP = NGRP * 128;
     constexpr int LDG = WP + 1;
@@ -736,6 +744,7 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
                     mC[l] = acc_grads ? mC[l] + dbias : dbias;
                 } else {
                     float w_ = bias, m_ = mC[l], v_ = vC[l];
+                    if (MODE == PV_MODE_TRAIN_ACC) dbias += gC[l];
                     pv_adam(w_, m_, v_, dbias, alpha, adam);
                     cb[l] = w_;
                     mC[l] = m_;
@@ -782,14 +791,16 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
                     const int off = (w * 4 + q) * 64 + lane;
                     if (MODE == PV_MODE_GRAD) {
                         f32x4 gq = {dv[q * 4 + 0], dv[q * 4 + 1], dv[q * 4 + 2], dv[q * 4 + 3]};
-                        if (acc_grads) gq += dM2[off];
-                        dM2[off] = gq;
+                        if (acc_grads) gq += __builtin_nontemporal_load(dM2 + off);
+                        __builtin_nontemporal_store(gq, dM2 + off);
                     } else {
                         f32x4 wq = vv[w][q], mq = __builtin_nontemporal_load(tM + off), vq = __builtin_nontemporal_load(tVv + off);
+                        f32x4 ga = {0.f, 0.f, 0.f, 0.f};
+                        if (MODE == PV_MODE_TRAIN_ACC) ga = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gV) + gbase + off);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float w_ = wq[e], m_ = mq[e], v_ = vq[e];
-                            pv_adam(w_, m_, v_, dv[q * 4 + e], alpha, adam);
+                            pv_adam(w_, m_, v_, MODE == PV_MODE_TRAIN_ACC ? dv[q * 4 + e] + ga[e] : dv[q * 4 + e], alpha, adam);
                             wq[e] = w_;
                             mq[e] = m_;
                             vq[e] = v_;
@@ -916,7 +927,7 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
                                                    int nblk, int ngrp, const PvStep* st, PvAdam adam,
                                                    const uint8_t* __restrict__ geno, int64_t row_bytes,
                                                    const int* __restrict__ rows, int next_off, int next_n,
-                                                   float* __restrict__ fpart, int ts) {
+                                                   float* __restrict__ fpart, int ts, const float* __restrict__ gW) {
     constexpr int WG_UNITS = NWB * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [ngrp][32][WG_UNITS]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
@@ -976,15 +987,17 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
                 const int off = (w * 4 + q) * 64 + lane;
                 if (MODE == PV_MODE_GRAD) {
                     f32x4 gq = {0.5f * dw[q * 4 + 0], 0.5f * dw[q * 4 + 1], 0.5f * dw[q * 4 + 2], 0.5f * dw[q * 4 + 3]};
-                    if (acc_grads) gq += oM[off];
-                    oM[off] = gq;
+                    if (acc_grads) gq += __builtin_nontemporal_load(oM + off);
+                    __builtin_nontemporal_store(gq, oM + off);
                 } else {
                     f32x4 wq = __builtin_nontemporal_load(tW + off), mq = __builtin_nontemporal_load(tM + off),
                           vq = __builtin_nontemporal_load(tV + off);
+                    f32x4 ga = {0.f, 0.f, 0.f, 0.f};
+                    if (MODE == PV_MODE_TRAIN_ACC) ga = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gW) + t * (NWB * 256) + off);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float w_ = wq[e], m_ = mq[e], v_ = vq[e];
-                        pv_adam(w_, m_, v_, 0.5f * dw[q * 4 + e], alpha, adam);
+                        pv_adam(w_, m_, v_, MODE == PV_MODE_TRAIN_ACC ? 0.5f * dw[q * 4 + e] + ga[e] : 0.5f * dw[q * 4 + e], alpha, adam);
                         wq[e] = w_;
                         mq[e] = m_;
                         vq[e] = v_;
@@ -1017,41 +1030,6 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
             const int w = e >> 10, r = (e >> 6) & 15, ln = e & 63;
             p[PV_ROW(r, ln >> 5) * ldf + w * 32 + (ln & 31)] = sum;
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Adam from accumulated gradients (batches above 32 rows).  Wide tensors: tile-interleaved W|m|v copy `cur` ->
-// copy `nxt`, gradient in plain tiles; linear tensors in place.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pvk_apply_wide(const f32x4* __restrict__ cur, f32x4* __restrict__ nxt,
-                                                      const f32x4* __restrict__ g, int64_t ntiles, int tile4,
-                                                      const PvStep* st, PvAdam adam) {
-    const float alpha = st->alpha;
-    const int64_t n4 = ntiles * tile4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const int64_t t = i / tile4, o = t * 3 * tile4 + (i - t * tile4);
-        f32x4 w = __builtin_nontemporal_load(cur + o), m = __builtin_nontemporal_load(cur + o + tile4),
-              v = __builtin_nontemporal_load(cur + o + 2 * tile4), gq = __builtin_nontemporal_load(g + i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float w_ = w[e], m_ = m[e], v_ = v[e];
-            pv_adam(w_, m_, v_, gq[e], alpha, adam);
-            w[e] = w_; m[e] = m_; v[e] = v_;
-        }
-        __builtin_nontemporal_store(w, nxt + o);
-        __builtin_nontemporal_store(m, nxt + o + tile4);
-        __builtin_nontemporal_store(v, nxt + o + 2 * tile4);
-    }
-}
-
-__global__ __launch_bounds__(256) void pvk_apply_lin(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
-                                                     const float* __restrict__ g, int64_t n, const PvStep* st, PvAdam adam) {
-    const float alpha = st->alpha;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float w_ = w[i], m_ = m[i], v_ = v[i];
-        pv_adam(w_, m_, v_, g[i], alpha, adam);
-        w[i] = w_; m[i] = m_; v[i] = v_;
     }
 }
 

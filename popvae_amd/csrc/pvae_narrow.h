@@ -30,6 +30,7 @@ struct PvBwdOp {
     const float* in;     // layer input  [32][kin]
     const float* Y;      // layer output [32][nout]
     float* dpre;         // dLoss/d(pre-activation) [32][nout]: written by the chain kernel, read by pvk_narrow_adam
+    const float *gW, *gB;  // MODE_TRAIN_ACC: gradients accumulated over the earlier tiles of the batch
     int kin, nout, act, kind;
 };
 
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                     op.mB[tid] = st->acc ? op.mB[tid] + g : g;
                 } else {
                     float w_ = op.B[tid], m_ = op.mB[tid], v_ = op.vB[tid];
+                    if (MODE == PV_MODE_TRAIN_ACC) g += op.gB[tid];
                     pv_adam(w_, m_, v_, g, alpha, adam);
                     op.B[tid] = w_;
                     op.mB[tid] = m_;
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict_
     const float alpha = st->alpha;
     const int voff = (kb * 32 + 4 * h) * N + nb * 32 + c;
     float wv[16], mv[16], vv[16];
-    if (MODE == PV_MODE_TRAIN) {
+    if (MODE != PV_MODE_GRAD) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ro = ((r & 3) + 8 * (r >> 2)) * N;
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict_
             (op.mW + ro)[voff] = st->acc ? (op.mW + ro)[voff] + acc[r] : acc[r];
         } else {
             float w_ = wv[r], m_ = mv[r], v_ = vv[r];
-            pv_adam(w_, m_, v_, acc[r], alpha, adam);
+            pv_adam(w_, m_, v_, MODE == PV_MODE_TRAIN_ACC ? acc[r] + (op.gW + ro)[voff] : acc[r], alpha, adam);
             (op.W + ro)[voff] = w_;
             (op.mW + ro)[voff] = m_;
             (op.vW + ro)[voff] = v_;
@@ -560,6 +562,7 @@ __global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict_
             op.mB[n] = st->acc ? op.mB[n] + g : g;
         } else {
             float w_ = op.B[n], m_ = op.mB[n], v_ = op.vB[n];
+            if (MODE == PV_MODE_TRAIN_ACC) g += op.gB[n];
             pv_adam(w_, m_, v_, g, alpha, adam);
             op.B[n] = w_;
             op.mB[n] = m_;
