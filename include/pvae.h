@@ -119,6 +119,10 @@ int pvae_restore_best(pvae_engine* e);
  * mode: 0 = train, 1 = eval (stage C only finalises the loss), 2 = gradients only, 3 = encode (A then
  * pvae_stage_encode).  With world == 1 pvae_train_step is exactly A,B,C back to back. */
 int pvae_exchange_buffer(pvae_engine* e, int which, void** device_ptr, int64_t* n_floats);
+/* host-staged exchange for transports that cannot take device pointers (MPI without GPU support, gloo, tests):
+ * copies exchange buffer `which` to the host (to_device == 0) or back (to_device != 0), ordered with the stages on
+ * the engine stream; n_floats must equal the buffer's size.  No counterpart in the reference (it has no multi-GPU path). */
+int pvae_exchange_copy(pvae_engine* e, int which, float* host, int64_t n_floats, int to_device);
 int pvae_stage_a(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, int mode);
 int pvae_stage_b(pvae_engine* e, int mode);
 int pvae_stage_c(pvae_engine* e, int mode, float* out3);

@@ -1344,6 +1344,18 @@ int pvae_exchange_buffer(pvae_engine* e, int which, void** device_ptr, int64_t* 
     return set_err(e, -2, "exchange buffer %d", which);
 }
 
+int pvae_exchange_copy(pvae_engine* e, int which, float* host, int64_t n_floats, int to_device) {
+    void* d;
+    int64_t n;
+    int rc;
+    if ((rc = pvae_exchange_buffer(e, which, &d, &n))) return rc;
+    if (!host || n_floats != n) return set_err(e, -2, "exchange buffer %d holds %lld floats, caller passed %lld", which, (long long)n, (long long)n_floats);
+    if (to_device) HIPCHK(hipMemcpyAsync(d, host, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    else HIPCHK(hipMemcpyAsync(host, d, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
 int pvae_stage_a(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, int mode) {
     int rc;
     if (mode == 3) {

@@ -19,7 +19,7 @@ ENGINE_SYMBOLS = [
     "pvae_synchronize", "pvae_load_genotypes", "pvae_num_tensors", "pvae_tensor_shape", "pvae_set_tensor",
     "pvae_get_tensor", "pvae_init_weights", "pvae_get_moment", "pvae_reset_optimizer", "pvae_set_lr", "pvae_get_lr",
     "pvae_train_step", "pvae_eval_step", "pvae_grad_step", "pvae_get_grad", "pvae_train_epoch", "pvae_encode",
-    "pvae_decode", "pvae_pca_gram", "pvae_snapshot_best", "pvae_restore_best", "pvae_exchange_buffer", "pvae_stage_a", "pvae_stage_b",
+    "pvae_decode", "pvae_pca_gram", "pvae_snapshot_best", "pvae_restore_best", "pvae_exchange_buffer", "pvae_exchange_copy", "pvae_stage_a", "pvae_stage_b",
     "pvae_stage_c", "pvae_stage_encode", "pvae_set_timing", "pvae_get_timing",
 ]
 
@@ -76,6 +76,7 @@ def lib():
         L.pvae_snapshot_best.argtypes = [vp]
         L.pvae_restore_best.argtypes = [vp]
         L.pvae_exchange_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(i64)]
+        L.pvae_exchange_copy.argtypes = [vp, C.c_int, _f32p, i64, C.c_int]
         L.pvae_stage_a.argtypes = [vp, _i32p, i32, _fopt, C.c_int]
         L.pvae_stage_b.argtypes = [vp, C.c_int]
         L.pvae_stage_c.argtypes = [vp, C.c_int, _fopt]
@@ -270,6 +271,16 @@ class Engine:
         p, n = C.c_void_p(), C.c_int64()
         self._ck(lib().pvae_exchange_buffer(self._h, which, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def exchange_read(self, which):
+        """Host copy of exchange buffer ``which`` (transports without device-pointer support, tests)."""
+        a = np.empty(self.exchange_buffer(which)[1], np.float32)
+        self._ck(lib().pvae_exchange_copy(self._h, which, a, a.size, 0))
+        return a
+
+    def exchange_write(self, which, a):
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+        self._ck(lib().pvae_exchange_copy(self._h, which, a, a.size, 1))
 
     def stage_a(self, rows, eps, mode):
         rows = np.ascontiguousarray(rows, dtype=np.int32)

@@ -1,0 +1,174 @@
+"""Parity at BASELINE.json's full SNP counts (configs C2, C3, C4): the HIP path through the C ABI against
+
+  * the float64 oracle directly (one forward/backward at 100k, 500k x width 512 and 1M SNPs: the oracle's BLAS
+    needs a few seconds there; the sample count is kept small, the kernels only ever see the batch's 32 rows), and
+  * size-independent properties: a repeated step is bitwise reproducible, the C-side epoch loop (first-layer
+    forward fused into the previous step's wide backward) ends in the same weights as step-by-step calls, SNP
+    shards add up to the unsharded result (linearity of both exchange points), and the first fused Adam
+    update equals the closed form  -lr * g / (|g| + eps / sqrt(1 - beta2))  of the engine's own gradient.
+
+fp32 tolerance 1e-4 relative (north_star) on loss and on every gradient tensor (relative to max |g|)."""
+import numpy as np
+import pytest
+
+from oracle import popvae_oracle as O
+from popvae_amd import engine, prep
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _codes(N, L, seed):
+    g = np.random.default_rng(seed)
+    f = np.clip(g.beta(0.5, 0.5, L), 0.02, 0.98).astype(np.float32)
+    return ((g.random((N, L), dtype=np.float32) < f).astype(np.uint8)
+            + (g.random((N, L), dtype=np.float32) < f).astype(np.uint8))
+
+
+def _pack(codes):
+    N, L = codes.shape
+    nb = (L + 31) // 32 * 8
+    c = np.zeros((N, nb * 4), np.uint8)
+    c[:, :L] = codes
+    c = c.reshape(N, nb, 4)
+    return np.ascontiguousarray(c[:, :, 0] | (c[:, :, 1] << 2) | (c[:, :, 2] << 4) | (c[:, :, 3] << 6))
+
+
+def _relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def test_pack_helper_matches_front_end():
+    codes = _codes(5, 1003, 1)
+    assert np.array_equal(_pack(codes), prep.pack_dc(codes * 0.5))
+
+
+@pytest.mark.parametrize("name,L,W,D,n", [
+    ("C2", 100_000, 128, 6, 32),
+    ("C4", 1_000_000, 128, 6, 32),
+    ("C4-short-batch", 1_000_000, 128, 6, 13),   # 2253 % 32 = 13: the epoch's last batch at C4
+    ("C3", 500_000, 512, 6, 32),
+    ("C5", 200_000, 256, 5, 32),
+])
+def test_full_size_loss_and_gradients_vs_oracle(name, L, W, D, n):
+    N, K = 40, 2
+    codes = _codes(N, L, seed=L % 1000 + W)
+    w = O.init_weights(L, W, D, K, seed=7, dtype=np.float32)
+    g = np.random.default_rng(5)
+    for t in w:
+        if t.ndim == 1:
+            t += g.normal(0, 0.05, t.shape).astype(np.float32)
+    rows = g.choice(N, n, replace=False).astype(np.int32)
+    eps = g.normal(size=(n, K)).astype(np.float32)
+    e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=32, seed=0)
+    e.load_genotypes(_pack(codes))
+    e.set_weights(w)
+    loss, recon, kl = e.grad_step(rows, eps)
+    got = e.get_grads()
+    w64 = [x.astype(np.float64) for x in w]
+    c = O.forward(w64, codes[rows] * 0.5, eps.astype(np.float64), D, K)
+    grads = O.backward(w64, c, D, K)
+    assert abs(loss - c["loss"]) <= RTOL * abs(c["loss"]), (loss, c["loss"])
+    assert abs(recon - c["recon"].mean()) <= RTOL * abs(c["recon"].mean())
+    for i, (a, b) in enumerate(zip(got, grads)):
+        assert a.shape == b.shape
+        assert _relerr(a, b) <= RTOL, (name, i, _relerr(a, b))
+    del grads, c, w64
+    # the same step again is bitwise reproducible (fixed-order split-K / split-N reductions)
+    loss2, _, _ = e.grad_step(rows, eps)
+    assert loss2 == loss
+    for a, b in zip(e.get_grads(), got):
+        assert np.array_equal(a, b)
+    # first fused Adam update from zero moments = closed form of the engine's own gradient
+    lr, eps_hat = 1e-3, 1e-7 / np.sqrt(1 - 0.999)
+    l3, _, _ = e.train_step(rows, eps)
+    assert l3 == loss
+    for i, (a, b, gr) in enumerate(zip(e.get_weights(), w, got)):
+        gr = gr.astype(np.float64)
+        want = -lr * gr / (np.abs(gr) + eps_hat)
+        # float32 weights of magnitude <= ~1: the stored update carries a rounding error of ~6e-8 * |w|
+        assert np.abs((a.astype(np.float64) - b) - want).max() <= 1e-4 * lr + 1.2e-7 * max(1.0, np.abs(b).max()), (name, i)
+    e.close()
+
+
+@pytest.mark.parametrize("L,W,D", [(1_000_000, 128, 6), (500_000, 512, 6)])
+def test_epoch_loop_equals_stepwise_at_full_size(L, W, D):
+    """pvae_train_epoch (next step's first-layer forward rides on the wide encoder backward) against a loop of
+    pvae_train_step calls: same permutation, same noise stream -> same losses and the same weights."""
+    N, K, steps = 150, 2, 4
+    packed = _pack(_codes(N, L, seed=3))
+    perm = np.random.default_rng(1).permutation(N)[:steps * 32 - 11].astype(np.int32)  # short last batch
+    outs = []
+    for mode in ("epoch", "steps"):
+        e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=32, seed=9)
+        e.load_genotypes(packed)
+        e.init_weights(3)
+        e.lr = 1e-4
+        if mode == "epoch":
+            loss, _ = e.train_epoch(perm, np.zeros(0, np.int32))
+        else:
+            ls = [e.train_step(perm[i:i + 32])[0] for i in range(0, len(perm), 32)]
+            loss = float(np.mean(np.array(ls, np.float32)))
+        wts = e.get_weights()
+        outs.append((loss, [wts[0], wts[2], wts[-2], wts[-1]]))
+        e.close()
+        del wts
+    (la, wa), (lb, wb) = outs
+    assert np.isfinite(la) and abs(la - lb) <= 1e-6 * abs(lb), (la, lb)
+    for i, (a, b) in enumerate(zip(wa, wb)):
+        # both paths sum the same partials; allow float32 re-association only (updates are ~1e-4 per step)
+        assert np.abs(a - b).max() <= 1e-6, (i, np.abs(a - b).max())
+
+
+def test_snp_shards_add_up_at_full_size():
+    """Linearity of the two exchange points at 1M SNPs: two engines holding half of the SNP axis each, driven
+    through the staged C ABI with the host adding their exchange buffers (pvae_exchange_copy), reproduce the unsharded loss and
+    the unsharded gradients (wide tensors: the matching slices)."""
+    from popvae_amd.dist import shard_bounds, shard_packed
+    L, W, D, K, N, n = 1_000_000, 128, 6, 2, 40, 32
+    codes = _codes(N, L, seed=11)
+    packed = _pack(codes)
+    g = np.random.default_rng(2)
+    rows = g.choice(N, n, replace=False).astype(np.int32)
+    eps = g.normal(size=(n, K)).astype(np.float32)
+    w = O.init_weights(L, W, D, K, seed=4, dtype=np.float32)
+    full = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=32, seed=0)
+    full.load_genotypes(packed)
+    full.set_weights(w)
+    loss, recon, kl = full.grad_step(rows, eps)
+    gf = full.get_grads()
+    full.close()
+    bounds = shard_bounds(L, 2)
+    engs = []
+    for r, (lo, hi) in enumerate(bounds):
+        e = engine.Engine(n_snps=hi - lo, width=W, depth=D, latent_dim=K, batch_size=32, seed=0,
+                          n_snps_global=L, snp_offset=lo, rank=r, world=2)
+        e.load_genotypes(shard_packed(packed, L, lo, hi))
+        ws = list(w)
+        ws[0], ws[-2], ws[-1] = (np.ascontiguousarray(w[0][lo:hi]), np.ascontiguousarray(w[-2][:, lo:hi]),
+                                 np.ascontiguousarray(w[-1][lo:hi]))
+        e.set_weights(ws)
+        engs.append(e)
+
+    def exchange(which):   # the all-reduce, staged through the host in rank order
+        s = engs[0].exchange_read(which) + engs[1].exchange_read(which)
+        for e in engs:
+            e.exchange_write(which, s)
+
+    for e in engs:
+        e.stage_a(rows, eps, engine.MODE_GRAD)
+    exchange(0)
+    for e in engs:
+        e.stage_b(engine.MODE_GRAD)
+    exchange(1)
+    outs = [e.stage_c(engine.MODE_GRAD, True) for e in engs]
+    assert outs[0] == outs[1]
+    assert abs(outs[0][0] - loss) <= 1e-6 * abs(loss), (outs[0][0], loss)
+    for r, ((lo, hi), e) in enumerate(zip(bounds, engs)):
+        gs = e.get_grads()
+        ref = list(gf)
+        ref[0], ref[-2], ref[-1] = gf[0][lo:hi], gf[-2][:, lo:hi], gf[-1][lo:hi]
+        for i, (a, b) in enumerate(zip(gs, ref)):
+            assert _relerr(a, b) <= 1e-5, (r, i, _relerr(a, b))
+        e.close()
