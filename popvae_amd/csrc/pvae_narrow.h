@@ -4,15 +4,16 @@
 // the KL term (:419-421) and their backward + Adam are a few hundred KFLOP on 64 KB matrices: launch- and
 // latency-bound, not throughput-bound.  Two kernels (forward, backward) walk an op table with the batch
 // activations resident in LDS, instead of ~26 small launches per step.  One workgroup of 8 waves:
-//   * weights go straight from global memory (L2-resident after the first step) into MFMA B operands;
+//   * weights go straight from global memory (L2-resident after the warm-up role) into MFMA B operands;
 //     the next layer's operands are loaded while the current layer computes;
-//   * A operands (activations / dpre) come from LDS, row stride 129 floats (conflict-free column reads);
-//   * split-K partial accumulators meet in LDS and are summed in a fixed order (deterministic).
+//   * A operands (activations / dpre) come from LDS with ds_read_b128, row stride 132 floats;
+//   * every wave owns 16 output columns of a layer (v_mfma_f32_16x16x4_f32): no partial sums, one barrier per layer,
+//     a fixed summation order (deterministic).
 // Wider layers (width 256/512) use the per-layer kernels in pvae_kernels.h, which spread a layer over CUs.
 #pragma once
 #include "pvae_kernels.h"
 
-#define PVN_LD 129
+#define PVN_LD 132
 #define PVN_THREADS 512
 
 enum { PVN_DENSE = 0, PVN_BIAS_ACT = 1, PVN_REPARAM = 2, PVN_FIRST_BIAS = 3 };
@@ -36,10 +37,10 @@ struct PvBwdOp {
 
 #define PVN_MAXOPS 64
 __host__ __device__ inline size_t pvn_lds_fwd() {
-    return (size_t)(32 * PVN_LD + 32 * 1024 + 128) * 4 + PVN_MAXOPS * sizeof(PvFwdOp);
+    return (size_t)(2 * 32 * PVN_LD) * 4 + PVN_MAXOPS * sizeof(PvFwdOp);
 }
 __host__ __device__ inline size_t pvn_lds_bwd() {
-    return (size_t)(2 * 32 * PVN_LD + 8 * 1024) * 4 + PVN_MAXOPS * sizeof(PvBwdOp);
+    return (size_t)(2 * 32 * PVN_LD) * 4 + PVN_MAXOPS * sizeof(PvBwdOp);
 }
 
 // The op table is cold in every launch (each step streams gigabytes through the caches in between), and a
@@ -80,15 +81,6 @@ __device__ unsigned long long pvn_trace_buf[2048];
 #define PVN_T(slot) do {} while (0)
 #endif
 
-// (row b, column cc) of a 32x32 accumulator block -> index of [reg][lane] storage
-__device__ __forceinline__ int pvn_frag_index(int b, int cc) {
-    const int h = (b >> 2) & 1, r = (b & 3) + 4 * (b >> 3);
-    return r * 64 + h * 32 + cc;
-}
-
-// Element ownership for [32][n] tiles (no integer division): thread t owns rows (t>>5) and (t>>5)+16,
-// columns (t&31) + 32*j.  32 consecutive threads touch 128 contiguous bytes / 32 distinct LDS banks.
-
 // 32 MFMA B operands of a lane as two SSA vectors (a float[32] passed by reference ends up in scratch)
 struct PvW32 {
     f32x16 lo, hi;
@@ -101,95 +93,72 @@ struct PvW32 {
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
-// forward.  One CU pulls ~64 KB of weights per layer through its own L1, which costs as much as the layer's
-// MFMAs; so the loads are 16 B per lane (1 KB per wave instruction) and issued one layer ahead.
-//   wave w owns the k-slice [w*K/8, (w+1)*K/8) of the contraction and ALL NB = nout/32 column blocks;
-//   block t holds the columns {NB*c + t : c < 32}, so that one NB-wide vector load per lane and k-step feeds
-//   NB MFMAs.  The 8 k-slice partials are summed through LDS in wave order.
-// ops[0] = BIAS_ACT (h1 = elu(P + b1)), hidden layers, heads, REPARAM (+KL), decoder layers; nops may stop
-// after REPARAM (encoder.predict).
+// One dense layer on one CU is bound by the fp32 matrix pipe: 32 x 128 x 128 MACs at 128 MAC/cycle/CU = 4096
+// cycles (1.7 us) -- so everything else (operand loads, reductions, barriers) has to stay off the critical path:
+//   * the OUTPUT columns are split over the 8 waves (16 columns each, v_mfma_f32_16x16x4_f32, two 16-row tiles):
+//     no cross-wave reduction, no partial sums through LDS, ONE barrier per layer;
+//   * the contraction index is permuted so that lane group q = lane >> 4 owns the contiguous quarter
+//     [q * KS, (q + 1) * KS) of it (KS = kin / 4): the A operands of a layer are 2 x KS/4 ds_read_b128 per lane from
+//     the LDS-resident activations (row stride 132 floats: 16 consecutive lanes cover all 64 banks);
+//   * the next layer's B operands (<= 32 VGPRs per lane) are loaded from global memory (L2-resident after the
+//     warm-up role below) while the current layer's MFMAs run; activations ping-pong between two LDS buffers.
+// Accumulator layout of 16x16x4: lane (n = lane & 15, q = lane >> 4) holds rows 4q + r, r < 4, of column n.
 // ---------------------------------------------------------------------------------------------
-template <int NB>
-__device__ __forceinline__ PvW32 pvn_fwd_load(PvW32 w, const float* W, int N, int k0, int steps, int c, int h) {
-    // NOTE: no per-load guards.  A load under a (even wave-uniform) runtime condition makes hipcc branch around it
-    // and wait vmcnt(0) per element -- 8 serial memory round trips; steps beyond `steps` re-load the last row.
+template <int KS>
+__device__ __forceinline__ void pvn_mma(f32x4& acc0, f32x4& acc1, const float* a0, const float* a1, const PvW32& w) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        {
-            const int sc = s < steps ? s : steps - 1;
-            const float* src = W + (k0 + 2 * sc + h) * N + NB * c;
-            if (NB == 4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+    for (int q = 0; q < KS / 4; ++q) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(a0 + 4 * q);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(a1 + 4 * q);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) PVN_WSET(w, s * 4 + t, v[t]);
-            } else if (NB == 2) {
-                const float2 v = *reinterpret_cast<const float2*>(src);
-                PVN_WSET(w, s * 4, v.x);
-                PVN_WSET(w, s * 4 + 1, v.y);
-            } else {
-#pragma unroll
-                for (int t = 0; t < NB; ++t) PVN_WSET(w, s * 4 + t, src[t]);
-            }
+        for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], PVN_W(w, 4 * q + e), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], PVN_W(w, 4 * q + e), acc1, 0, 0, 0);
         }
+    }
+}
+// forward B operands: W[kin][nout] row-major, lane (n, q) takes W[q * KS + s][col], s < KS (a strided column walk;
+// 16 lanes share a 64-byte segment).  NOTE: no per-load guards -- a load under a runtime condition makes hipcc
+// branch around it and wait vmcnt(0) per element; whole inactive waves skip the block instead.
+template <int KS>
+__device__ __forceinline__ PvW32 pvn_load_cols(PvW32 w, const float* src, int N) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) PVN_WSET(w, s, src[s * N]);
+    return w;
+}
+// backward B operands: dIn = dpre * W^T, lane (k, q) takes the contiguous run W[k][q * KS + s], s < KS
+template <int KS>
+__device__ __forceinline__ PvW32 pvn_load_contig(PvW32 w, const float* src) {
+#pragma unroll
+    for (int q = 0; q < KS / 4; ++q) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(src)[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) PVN_WSET(w, 4 * q + e, v[e]);
     }
     return w;
 }
-
-template <int NB>
-__device__ __forceinline__ void pvn_fwd_dense(const PvFwdOp& op, const PvW32& w, float* act, float* red,
-                                              const float* bias_s, int tid) {
-    const int wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
-    const int row0 = tid >> 5, col0 = tid & 31;
-    const int kw = op.kin >> 3, steps = kw >> 1, k0 = wave * kw;
-    f32x16 acc[NB];
-#pragma unroll
-    for (int t = 0; t < NB; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float a[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) a[s] = act[c * PVN_LD + ((k0 + 2 * s + h) & 127)];  // s >= steps: unused
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-        if (s < steps) {
-#pragma unroll
-            for (int t = 0; t < NB; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], PVN_W(w, s * 4 + t), acc[t], 0, 0, 0);
-        }
-#pragma unroll
-    for (int t = 0; t < NB; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[((wave * NB + t) * 16 + r) * 64 + lane] = acc[t][r];
-    __syncthreads();  // all reads of `act` and all partials are done
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int b = row0 + 16 * rr;
-        const int fi = pvn_frag_index(b, col0);
-#pragma unroll
-        for (int t = 0; t < NB; ++t) {
-            float x = red[t * 1024 + fi];
-#pragma unroll
-            for (int wv = 1; wv < 8; ++wv) x += red[(wv * NB + t) * 1024 + fi];
-            const int n = NB * col0 + t;
-            x += bias_s[n];
-            const float y = op.act == PV_ACT_ELU ? pv_elu(x) : x;
-            act[b * PVN_LD + n] = y;
-            op.out[b * op.nout + n] = y;
-        }
+#define PVN_SWITCH(ks, ...)                                      \
+    switch ((ks) >> 3) {                                         \
+        case 1: { constexpr int S_ = 8; __VA_ARGS__; } break;    \
+        case 2: { constexpr int S_ = 16; __VA_ARGS__; } break;   \
+        case 3: { constexpr int S_ = 24; __VA_ARGS__; } break;   \
+        default: { constexpr int S_ = 32; __VA_ARGS__; } break;  \
     }
-}
 
+// ---------------------------------------------------------------------------------------------
+// forward.  ops[0] = BIAS_ACT (h1 = elu(P + b1)), hidden layers, heads, REPARAM (+KL), decoder layers; nops may
+// stop after REPARAM (encoder.predict); op0 > 0 starts behind REPARAM with z (decoder.predict).
+// ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __restrict__ ops, int op0, int nops,
                                                               const float* __restrict__ P,
                                                               const float* __restrict__ eps, int K, int Kz,
                                                               float* __restrict__ z_out, float* __restrict__ kl_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* act = smem;                   // [32][PVN_LD]
-    float* red = smem + 32 * PVN_LD;     // [8 waves][NB][16][64]
-    float* bias_s = red + 32 * 1024;     // [128]
-    int* ops_s = reinterpret_cast<int*>(bias_s + 128);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
-    const int row0 = tid >> 5, col0 = tid & 31;
+    float* cur = smem;                   // [32][PVN_LD]
+    float* nxt = smem + 32 * PVN_LD;     // [32][PVN_LD]
+    int* ops_s = reinterpret_cast<int*>(smem + 2 * 32 * PVN_LD);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int n0 = wave * 16;
     if (blockIdx.x != 0) {
         const int p = (int)(blockIdx.x >> 3) - 1;
         if ((blockIdx.x & 7) == 0 && p < nops) {
@@ -208,19 +177,16 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
     auto prefetch = [&](int i) {
         if (i >= nops) return;
         const PvFwdOp op = pvn_get_op<PvFwdOp>(ops_s, i);
-        bnext = op.b[tid < op.nout ? tid : op.nout - 1];  // op.b is never null (REPARAM carries a dummy)
+        if (op.kind == PVN_REPARAM || n0 >= op.nout) return;
+        bnext = op.b[n0 + n];
         if (op.kind != PVN_DENSE) return;
-        const int kw = op.kin >> 3, steps = kw >> 1, k0 = wave * kw;
-        switch (op.nout >> 5) {
-            case 1: wnext = pvn_fwd_load<1>(wnext, op.W, op.nout, k0, steps, c, h); break;
-            case 2: wnext = pvn_fwd_load<2>(wnext, op.W, op.nout, k0, steps, c, h); break;
-            case 3: wnext = pvn_fwd_load<3>(wnext, op.W, op.nout, k0, steps, c, h); break;
-            default: wnext = pvn_fwd_load<4>(wnext, op.W, op.nout, k0, steps, c, h); break;
-        }
+        const int ks = op.kin >> 2;
+        const float* src = op.W + (q * ks) * op.nout + n0 + n;
+        PVN_SWITCH(ks, wnext = pvn_load_cols<S_>(wnext, src, op.nout));
     };
     if (op0 > 0) {  // decoder.predict: start behind REPARAM with z (already in z_out) as the activation
         if (tid < 32)
-            for (int k = 0; k < Kz; ++k) act[tid * PVN_LD + k] = z_out[tid * Kz + k];
+            for (int k = 0; k < Kz; ++k) cur[tid * PVN_LD + k] = z_out[tid * Kz + k];
         __syncthreads();
     }
     prefetch(op0);
@@ -228,46 +194,30 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
         const PvFwdOp op = pvn_get_op<PvFwdOp>(ops_s, i);
         PVN_T(i * 8 + 0);
         const PvW32 wcur = wnext;
-#ifdef PVN_TRACE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PVN_T(i * 8 + 1);
-#endif
-        if (tid < 128) bias_s[tid] = bnext;  // read after this op's first barrier at the earliest
-        prefetch(i + 1);
-        PVN_T(i * 8 + 5);
+        const float bcur = bnext;
         const int N = op.nout;
-        if (op.kind == PVN_BIAS_ACT) {
-            float pv[2][4];
+        float pv[2][4];
+        if (op.kind == PVN_BIAS_ACT && n0 < N) {
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    pv[rr][j] = P[(row0 + 16 * rr) * N + (j * 32 < N ? j : 0) * 32 + col0];  // clamped, never guarded
-            __syncthreads();
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j * 32 < N) {
-                        const int b = row0 + 16 * rr, n = j * 32 + col0;
-                        const float x = pv[rr][j] + bias_s[n];
-                        const float y = op.act == PV_ACT_ELU ? pv_elu(x) : x;
-                        act[b * PVN_LD + n] = y;
-                        op.out[b * N + n] = y;
-                    }
-        } else if (op.kind == PVN_REPARAM) {
-            // act holds the heads output: cols [0,K) = z_mean, [K,2K) = z_log_var; replaced by z (padded to Kz)
+                for (int r = 0; r < 4; ++r) pv[t][r] = P[(16 * t + 4 * q + r) * N + n0 + n];
+        }
+        prefetch(i + 1);
+        PVN_T(i * 8 + 1);
+        if (op.kind == PVN_REPARAM) {
+            // cur holds the heads output: cols [0,K) = z_mean, [K,2K) = z_log_var; nxt gets z (padded to Kz)
             if (tid < 32) {
                 const int b = tid;
                 float mu[16], sv[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    mu[k] = k < K ? act[b * PVN_LD + k] : 0.f;
-                    sv[k] = k < K ? act[b * PVN_LD + K + k] : 0.f;
+                    mu[k] = k < K ? cur[b * PVN_LD + k] : 0.f;
+                    sv[k] = k < K ? cur[b * PVN_LD + K + k] : 0.f;
                 }
                 float acc = 0.f;
                 for (int k = 0; k < Kz; ++k) {
-                    act[b * PVN_LD + k] = 0.f;
+                    nxt[b * PVN_LD + k] = 0.f;
                     z_out[b * Kz + k] = 0.f;
                 }
 #pragma unroll
@@ -276,21 +226,43 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
                         const float es = expf(sv[k]);
                         const float zz = mu[k] + es * eps[b * K + k];  // exp(s), not exp(s/2): popvae.py:389
                         acc += 1.f + sv[k] - mu[k] * mu[k] - es;
-                        act[b * PVN_LD + k] = zz;
+                        nxt[b * PVN_LD + k] = zz;
                         z_out[b * Kz + k] = zz;
                     }
                 kl_out[b] = -0.5f * acc;
             }
-        } else {
-            PVN_T(i * 8 + 2);
-            switch (N >> 5) {
-                case 1: pvn_fwd_dense<1>(op, wcur, act, red, bias_s, tid); break;
-                case 2: pvn_fwd_dense<2>(op, wcur, act, red, bias_s, tid); break;
-                case 3: pvn_fwd_dense<3>(op, wcur, act, red, bias_s, tid); break;
-                default: pvn_fwd_dense<4>(op, wcur, act, red, bias_s, tid); break;
+        } else if (n0 < N) {
+            f32x4 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][r] = op.kind == PVN_BIAS_ACT ? pv[t][r] : 0.f;
+            if (op.kind == PVN_DENSE) {
+                const int ks = op.kin >> 2;
+                const float* a0 = cur + n * PVN_LD + q * ks;
+                PVN_SWITCH(ks, pvn_mma<S_>(acc[0], acc[1], a0, a0 + 16 * PVN_LD, wcur));
             }
+#ifdef PVN_TRACE
+            asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]));
+            PVN_T(i * 8 + 2);
+#endif
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int b = 16 * t + 4 * q + r;
+                    const float x = acc[t][r] + bcur;
+                    const float y = op.act == PV_ACT_ELU ? pv_elu(x) : x;
+                    nxt[b * PVN_LD + n0 + n] = y;
+                    op.out[b * N + n0 + n] = y;
+                }
         }
-        __syncthreads();
+        PVN_T(i * 8 + 3);
+        __syncthreads();  // nxt complete, every read of cur done
+        PVN_T(i * 8 + 4);
+        float* t_ = cur;
+        cur = nxt;
+        nxt = t_;
     }
 }
 
@@ -299,37 +271,11 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
 //   dpre = dY * act'(Y)  (saved to global for part 2),  dIn = dpre * W^T  -> dY of the next op.
 // Ops: decoder layers D..1, REPARAM (dz -> dmu, ds), heads, encoder layers D..2, FIRST_BIAS (dpre1 + b1 Adam).
 // dY of the first op = xch[0 .. 32*W0): the all-reduced decoder feedback; xch[32*W0] = summed BCE.
-// The weights are only READ here; part 2 (pvk_narrow_adam, one wave per 32x32 weight block, spread over the
-// chip) forms dW = in^T * dpre and applies Adam.  Splitting it this way keeps the 6 x 64 KB per layer of
-// W/m/v traffic off the single CU that walks the chain.
+// Same structure as the forward: wave w owns the 16 columns [16w, 16w + 16) of dIn, and the epilogue of op i turns
+// its tile of dIn straight into the NEXT op's dpre (times act'(Y), rows beyond the batch zeroed), in LDS for the
+// chain and in global memory for part 2.  The weights are only READ here; part 2 (pvk_narrow_adam, one wave per
+// 32x32 weight block, spread over the chip) forms dW = in^T * dpre and applies Adam.
 // ---------------------------------------------------------------------------------------------
-template <int STEPS>
-__device__ __forceinline__ PvW32 pvn_load_contig(PvW32 w, const float* src) {
-#pragma unroll
-    for (int q = 0; q < STEPS / 4; ++q) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(src)[q];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) PVN_WSET(w, 4 * q + e, v[e]);
-    }
-    return w;
-}
-template <int STEPS>
-__device__ __forceinline__ f32x16 pvn_mma(f32x16 acc, const float* a, const PvW32& w) {
-    float av[STEPS];
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) av[s] = a[s];
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], PVN_W(w, s), acc, 0, 0, 0);
-    return acc;
-}
-#define PVN_SWITCH(steps, ...)                                   \
-    switch ((steps) >> 3) {                                      \
-        case 1: { constexpr int S_ = 8; __VA_ARGS__; } break;    \
-        case 2: { constexpr int S_ = 16; __VA_ARGS__; } break;   \
-        case 3: { constexpr int S_ = 24; __VA_ARGS__; } break;   \
-        default: { constexpr int S_ = 32; __VA_ARGS__; } break;  \
-    }
-
 template <int MODE>
 __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __restrict__ ops, int nops,
                                                               const float* __restrict__ xch, int W0,
@@ -339,12 +285,11 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                                                               const PvStep* __restrict__ st, PvAdam adam,
                                                               float* __restrict__ out3, int update) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* dY_s = smem;
-    float* dp_s = smem + 32 * PVN_LD;
-    float* red = smem + 2 * 32 * PVN_LD;  // [8 waves][16][64]
-    int* ops_s = reinterpret_cast<int*>(red + 8 * 1024);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
-    const int row0 = tid >> 5, col0 = tid & 31;
+    float* cur = smem;
+    float* nxt = smem + 32 * PVN_LD;
+    int* ops_s = reinterpret_cast<int*>(smem + 2 * 32 * PVN_LD);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int n0 = wave * 16;
     if (blockIdx.x != 0) {
         const int p = (int)(blockIdx.x >> 3) - 1;
         if (update && (blockIdx.x & 7) == 0 && p < nops) {
@@ -368,102 +313,56 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     if (!update) return;
     __syncthreads();
 
-    // dIn[b][k] = sum_n dpre[b][n] W[k][n]: wave (kb, nq) owns k-block kb and half nq of the n range;
-    // lane (c, h) feeds contraction indices n0 + h*half + s, s < half (a contiguous run of W row kb*32 + c).
-    const int kb = wave >> 1, nq = wave & 1;
     PvW32 wnext;
-    float ynext[2][4];
 #pragma unroll
     for (int s = 0; s < 16; ++s) wnext.lo[s] = wnext.hi[s] = 0.f;
+    // B operands of op i: lane (k = n, q) of wave w reads W[16w + k][q * KS + s], KS = nout / 4
     auto prefetch = [&](int i) {
         if (i >= nops) return;
         const PvBwdOp op = pvn_get_op<PvBwdOp>(ops_s, i);
-        if (op.kind == PVN_REPARAM) return;
-        const int N = op.nout;
-        if (op.act == PV_ACT_ELU) {
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    ynext[rr][j] = op.Y[(row0 + 16 * rr) * N + (j * 32 < N ? j : 0) * 32 + col0];  // clamped
-        }
-        if (op.kind != PVN_DENSE || kb * 32 >= op.kin) return;
-        const int chunk = N >> 1, half = chunk >> 1;
-        const float* src = op.W + (kb * 32 + c) * N + nq * chunk + h * half;
-        PVN_SWITCH(half, wnext = pvn_load_contig<S_>(wnext, src));
+        if (op.kind != PVN_DENSE || n0 >= op.kin) return;
+        const int ks = op.nout >> 2;
+        const float* src = op.W + (n0 + n) * op.nout + q * ks;
+        PVN_SWITCH(ks, wnext = pvn_load_contig<S_>(wnext, src));
     };
     prefetch(0);
-    {
-        float xv[2][4];
+    {   // dpre of the first op from the exchanged decoder feedback
+        const PvBwdOp op = pvn_get_op<PvBwdOp>(ops_s, 0);
+        if (n0 < W0) {
+            float xv[2][4], yv[2][4];
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xv[rr][j] = xch[(row0 + 16 * rr) * W0 + (j * 32 < W0 ? j : 0) * 32 + col0];
+                for (int r = 0; r < 4; ++r) {
+                    const int b = 16 * t + 4 * q + r;
+                    xv[t][r] = xch[b * W0 + n0 + n];
+                    yv[t][r] = op.Y[b * W0 + n0 + n];
+                }
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j * 32 < W0) dY_s[(row0 + 16 * rr) * PVN_LD + j * 32 + col0] = xv[rr][j];
+                for (int r = 0; r < 4; ++r) {
+                    const int b = 16 * t + 4 * q + r;
+                    float d = b < nrows ? xv[t][r] : 0.f;
+                    if (op.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[t][r]);
+                    cur[b * PVN_LD + n0 + n] = d;
+                    op.dpre[b * W0 + n0 + n] = d;
+                }
+        }
     }
     __syncthreads();
 
     for (int i = 0; i < nops; ++i) {
         const PvBwdOp op = pvn_get_op<PvBwdOp>(ops_s, i);
-        const int N = op.nout, Kin = op.kin;
         const PvW32 wb = wnext;
-        float yv[2][4];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) yv[rr][j] = ynext[rr][j];
         prefetch(i + 1);
-        if (op.kind == PVN_REPARAM) {
-            // dY_s = dz [32][..]; result: d heads [32][Kh] (cols [0,K) dmu, [K,2K) ds, rest 0)
-            if (tid < 32) {
-                const int b = tid;
-                const bool valid = b < nrows;
-                float dmu[16], dsv[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    dmu[k] = 0.f;
-                    dsv[k] = 0.f;
-                    if (k < K && valid) {
-                        const float mu = heads[b * Kh + k], s = heads[b * Kh + K + k];
-                        const float es = expf(s), d = dY_s[b * PVN_LD + k];
-                        dmu[k] = d + mu * inv_b;
-                        dsv[k] = d * eps[b * K + k] * es + 0.5f * (es - 1.f) * inv_b;
-                    }
-                }
-                for (int k = 0; k < Kh; ++k) dY_s[b * PVN_LD + k] = 0.f;  // own row only
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k < K) {
-                        dY_s[b * PVN_LD + k] = dmu[k];
-                        dY_s[b * PVN_LD + K + k] = dsv[k];
-                    }
-            }
-            __syncthreads();
-            continue;
-        }
-        // dpre = dY * act'(Y), rows beyond the batch zeroed; kept in LDS and written out for part 2
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j * 32 < N) {
-                    const int b = row0 + 16 * rr, n = j * 32 + col0;
-                    float d = b < nrows ? dY_s[b * PVN_LD + n] : 0.f;
-                    if (op.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[rr][j]);
-                    dp_s[b * PVN_LD + n] = d;
-                    op.dpre[b * N + n] = d;
-                }
-        __syncthreads();
         if (op.kind == PVN_FIRST_BIAS) {
-            // dpre1 is what the wide encoder backward consumes; b1 gets its Adam step here
+            // cur = dpre1 (already in global memory for the wide encoder backward); b1 gets its Adam step here
+            const int N = op.nout;
             if (tid < N) {
                 float g = 0.f;
 #pragma unroll 8
-                for (int b = 0; b < 32; ++b) g += dp_s[b * PVN_LD + tid];
+                for (int b = 0; b < 32; ++b) g += cur[b * PVN_LD + tid];
                 if (MODE == PV_MODE_GRAD) {
                     op.mB[tid] = st->acc ? op.mB[tid] + g : g;
                 } else {
@@ -475,29 +374,74 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                     op.vB[tid] = v_;
                 }
             }
-            continue;
+            break;
         }
-        const int chunk = N >> 1, half = chunk >> 1;
-        if (kb * 32 < Kin) {
-            f32x16 acc;
+        const PvBwdOp nx = pvn_get_op<PvBwdOp>(ops_s, i + 1);  // the table always ends with FIRST_BIAS
+        if (op.kind == PVN_REPARAM) {
+            // cur = dz [32][Kz]; result: dpre of the heads op [32][Kh] (cols [0,K) dmu, [K,2K) ds, rest 0)
+            if (tid < 32) {
+                const int b = tid;
+                const bool valid = b < nrows;
+                float dmu[16], dsv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const float* a = dp_s + c * PVN_LD + nq * chunk + h * half;
-            PVN_SWITCH(half, acc = (pvn_mma<S_>(acc, a, wb)));
+                for (int k = 0; k < 16; ++k) {
+                    dmu[k] = 0.f;
+                    dsv[k] = 0.f;
+                    if (k < K && valid) {
+                        const float mu = heads[b * Kh + k], s = heads[b * Kh + K + k];
+                        const float es = expf(s), d = cur[b * PVN_LD + k];
+                        dmu[k] = d + mu * inv_b;
+                        dsv[k] = d * eps[b * K + k] * es + 0.5f * (es - 1.f) * inv_b;
+                    }
+                }
+                for (int k = 0; k < Kh; ++k) {
+                    nxt[b * PVN_LD + k] = 0.f;
+                    nx.dpre[b * Kh + k] = 0.f;
+                }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+                for (int k = 0; k < 16; ++k)
+                    if (k < K) {
+                        nxt[b * PVN_LD + k] = dmu[k];
+                        nxt[b * PVN_LD + K + k] = dsv[k];
+                        nx.dpre[b * Kh + k] = dmu[k];
+                        nx.dpre[b * Kh + K + k] = dsv[k];
+                    }
+            }
+        } else if (n0 < op.kin) {
+            const int Kin = op.kin, ks = op.nout >> 2;
+            const bool to_dpre = nx.kind != PVN_REPARAM;  // REPARAM consumes the raw dz
+            float yv[2][4];
+            if (to_dpre && nx.act == PV_ACT_ELU) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) yv[t][r] = nx.Y[(16 * t + 4 * q + r) * Kin + n0 + n];
+            }
+            f32x4 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+            const float* a0 = cur + n * PVN_LD + q * ks;
+            PVN_SWITCH(ks, pvn_mma<S_>(acc[0], acc[1], a0, a0 + 16 * PVN_LD, wb));
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int b = 16 * t + 4 * q + r;
+                    float d = acc[t][r];
+                    if (to_dpre) {
+                        if (nx.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[t][r]);
+                        if (b >= nrows) d = 0.f;
+                        nx.dpre[b * Kin + n0 + n] = d;
+                    }
+                    nxt[b * PVN_LD + n0 + n] = d;
+                }
         }
         __syncthreads();
-        // dIn = sum of the two n-halves -> dY of the next op
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int b = row0 + 16 * rr;
-            const int fi = pvn_frag_index(b, col0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j * 32 < Kin) dY_s[b * PVN_LD + j * 32 + col0] = red[(j * 2) * 1024 + fi] + red[(j * 2 + 1) * 1024 + fi];
-        }
-        __syncthreads();
+        float* t_ = cur;
+        cur = nxt;
+        nxt = t_;
     }
 }
 
