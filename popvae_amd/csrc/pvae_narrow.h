@@ -26,14 +26,27 @@ struct PvFwdOp {
 };
 
 struct PvBwdOp {
-    float *W, *mW, *vW;  // MODE_GRAD: mW = gradient dump, vW unused
-    float *B, *mB, *vB;
-    const float* in;     // layer input  [32][kin]
+    // -- read by the chain kernel for every op (the first PVN_BWD_LEAN dwords) --
+    float* W;            // [kin][nout]
     const float* Y;      // layer output [32][nout]
     float* dpre;         // dLoss/d(pre-activation) [32][nout]: written by the chain kernel, read by pvk_narrow_adam
-    const float *gW, *gB;  // MODE_TRAIN_ACC: gradients accumulated over the earlier tiles of the batch
     int kin, nout, act, kind;
+    // -- pvk_narrow_adam / FIRST_BIAS only --
+    float *mW, *vW;      // MODE_GRAD: mW = gradient dump, vW unused
+    float *B, *mB, *vB;
+    const float* in;     // layer input  [32][kin]
+    const float *gW, *gB;  // MODE_TRAIN_ACC: gradients accumulated over the earlier tiles of the batch
 };
+#define PVN_BWD_LEAN 10
+
+// Pointers that come out of an op descriptor have lost their address space: the compiler would use FLAT loads and
+// stores for them, which count on the LDS counter as well -- every wait for an LDS read would then also wait for the
+// prefetched weights.  These casts put them back into the global address space.
+typedef __attribute__((address_space(1))) float pvn_gf;
+typedef __attribute__((address_space(1))) f32x4 pvn_gf4;
+__device__ __forceinline__ const pvn_gf* pvn_g(const float* p) { return (const pvn_gf*)p; }
+__device__ __forceinline__ pvn_gf* pvn_g(float* p) { return (pvn_gf*)p; }
+__device__ __forceinline__ const pvn_gf4* pvn_g4(const float* p) { return (const pvn_gf4*)p; }
 
 #define PVN_MAXOPS 64
 __host__ __device__ inline size_t pvn_lds_fwd() {
@@ -74,6 +87,18 @@ __device__ __forceinline__ T pvn_get_op(const int* ops_s, int i) {
     return t;
 }
 
+// first ND dwords of descriptor i only (the rest of T stays zero)
+template <typename T, int ND>
+__device__ __forceinline__ T pvn_get_op_lean(const int* ops_s, int i) {
+    constexpr int NT = sizeof(T) / 4;
+    int d[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) d[k] = k < ND ? __builtin_amdgcn_readfirstlane(ops_s[i * NT + k]) : 0;
+    T t;
+    __builtin_memcpy(&t, d, sizeof(T));
+    return t;
+}
+
 #ifdef PVN_TRACE
 __device__ unsigned long long pvn_trace_buf[2048];
 #define PVN_T(slot) do { if (tid == 0) { pvn_trace_buf[2*(slot)] = wall_clock64(); pvn_trace_buf[2*(slot)+1] = clock64(); } } while (0)
@@ -104,38 +129,73 @@ struct PvW32 {
 //     warm-up role below) while the current layer's MFMAs run; activations ping-pong between two LDS buffers.
 // Accumulator layout of 16x16x4: lane (n = lane & 15, q = lane >> 4) holds rows 4q + r, r < 4, of column n.
 // ---------------------------------------------------------------------------------------------
-template <int KS>
-__device__ __forceinline__ void pvn_mma(f32x4& acc0, f32x4& acc1, const float* a0, const float* a1, const PvW32& w) {
+// The layer's MFMAs with the NEXT op's 32 B operands loaded in between (8 chunks of 4 spread over the KS/4
+// iterations): issued in one burst ahead of the MFMAs, 8 waves x 32 loads queue up in the CU's one address unit for
+// ~1 us before the first MFMA can issue.  The chunk index is clamped to the next op's own operand count (re-loading
+// its last chunk) so that no load sits under a condition; a wave with nothing to prefetch passes nks = 1, stride 0
+// and any valid address.  FWD: element s at nsrc[s * nstride]; else the contiguous run nsrc[s].
+template <int KS, bool FWD>
+__device__ __forceinline__ void pvn_mma(f32x4& acc0, f32x4& acc1, const float* a0, const float* a1, const PvW32& w,
+                                        PvW32& wn, const float* nsrc, int nstride, int nks) {
+    constexpr int NI = KS / 4;
+    f32x4 x0[NI], x1[NI];
 #pragma unroll
-    for (int q = 0; q < KS / 4; ++q) {
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(a0 + 4 * q);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(a1 + 4 * q);
+    for (int q = 0; q < NI; ++q) {
+        x0[q] = *reinterpret_cast<const f32x4*>(a0 + 4 * q);
+        x1[q] = *reinterpret_cast<const f32x4*>(a1 + 4 * q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+#pragma unroll
+        for (int c = q * 8 / NI; c < (q + 1) * 8 / NI; ++c) {
+            if (FWD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int sc = min(4 * c + e, nks - 1);
+                    PVN_WSET(wn, 4 * c + e, pvn_g(nsrc)[sc * nstride]);
+                }
+            } else {
+                const f32x4 v = pvn_g4(nsrc)[min(c, (nks >> 2) - 1)];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) PVN_WSET(wn, 4 * c + e, v[e]);
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], PVN_W(w, 4 * q + e), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], PVN_W(w, 4 * q + e), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[q][e], PVN_W(w, 4 * q + e), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[q][e], PVN_W(w, 4 * q + e), acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// the same 8 chunks without a layer to hide behind (first op, ops without MFMAs)
+template <bool FWD>
+__device__ __forceinline__ void pvn_prefetch_plain(PvW32& wn, const float* nsrc, int nstride, int nks) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (FWD) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) PVN_WSET(wn, 4 * c + e, pvn_g(nsrc)[min(4 * c + e, nks - 1) * nstride]);
+        } else {
+            const f32x4 v = pvn_g4(nsrc)[min(c, (nks >> 2) - 1)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) PVN_WSET(wn, 4 * c + e, v[e]);
         }
     }
 }
-// forward B operands: W[kin][nout] row-major, lane (n, q) takes W[q * KS + s][col], s < KS (a strided column walk;
-// 16 lanes share a 64-byte segment).  NOTE: no per-load guards -- a load under a runtime condition makes hipcc
-// branch around it and wait vmcnt(0) per element; whole inactive waves skip the block instead.
-template <int KS>
-__device__ __forceinline__ PvW32 pvn_load_cols(PvW32 w, const float* src, int N) {
-#pragma unroll
-    for (int s = 0; s < KS; ++s) PVN_WSET(w, s, src[s * N]);
-    return w;
-}
-// backward B operands: dIn = dpre * W^T, lane (k, q) takes the contiguous run W[k][q * KS + s], s < KS
-template <int KS>
-__device__ __forceinline__ PvW32 pvn_load_contig(PvW32 w, const float* src) {
-#pragma unroll
-    for (int q = 0; q < KS / 4; ++q) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(src)[q];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) PVN_WSET(w, 4 * q + e, v[e]);
-    }
-    return w;
+// Wait-count discipline.  gfx9 has ONE counter for vector loads and stores, and with both kinds outstanding the compiler
+// has to wait for everything at the first use of a loaded register; __syncthreads() adds a full drain per layer on top
+// (its workgroup fence covers global memory).  Either would put ~1 us of store-acknowledge / load latency between
+// two layers.  So per op: the next op's operands are loaded DURING this op's MFMAs, the counter is drained once right
+// AFTER the MFMAs (the loads have had the whole MFMA phase, the previous op's stores a whole op), only then does the
+// epilogue issue this op's stores, and the barrier between ops orders LDS only.
+#define PVN_DRAIN_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70) /* vmcnt(0), expcnt / lgkmcnt untouched */
+__device__ __forceinline__ void pvn_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+
 }
 #define PVN_SWITCH(ks, ...)                                      \
     switch ((ks) >> 3) {                                         \
@@ -171,41 +231,41 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
     __syncthreads();
 
     PvW32 wnext;
-    float bnext = 0.f;
 #pragma unroll
     for (int s = 0; s < 16; ++s) wnext.lo[s] = wnext.hi[s] = 0.f;
-    auto prefetch = [&](int i) {
-        if (i >= nops) return;
-        const PvFwdOp op = pvn_get_op<PvFwdOp>(ops_s, i);
-        if (op.kind == PVN_REPARAM || n0 >= op.nout) return;
-        bnext = op.b[n0 + n];
-        if (op.kind != PVN_DENSE) return;
-        const int ks = op.kin >> 2;
-        const float* src = op.W + (q * ks) * op.nout + n0 + n;
-        PVN_SWITCH(ks, wnext = pvn_load_cols<S_>(wnext, src, op.nout));
+    // where this lane's B operands of op `o` start (element s at src[s * stride], s < ks); a wave that has
+    // nothing to load for `o` gets a harmless address
+    const float* nsrc = P;
+    int nstride = 0, nks = 1;
+    auto aim = [&](const PvFwdOp& o) {
+        nsrc = P; nstride = 0; nks = 1;
+        if (o.kind != PVN_DENSE || n0 >= o.nout) return;
+        nks = o.kin >> 2;
+        nstride = o.nout;
+        nsrc = o.W + (q * nks) * o.nout + n0 + n;
     };
     if (op0 > 0) {  // decoder.predict: start behind REPARAM with z (already in z_out) as the activation
         if (tid < 32)
             for (int k = 0; k < Kz; ++k) cur[tid * PVN_LD + k] = z_out[tid * Kz + k];
         __syncthreads();
     }
-    prefetch(op0);
+    PvFwdOp op = pvn_get_op<PvFwdOp>(ops_s, op0);
+    aim(op);
+    pvn_prefetch_plain<true>(wnext, nsrc, nstride, nks);
+    PVN_DRAIN_VMEM();
     for (int i = op0; i < nops; ++i) {
-        const PvFwdOp op = pvn_get_op<PvFwdOp>(ops_s, i);
         PVN_T(i * 8 + 0);
         const PvW32 wcur = wnext;
-        const float bcur = bnext;
+        // this op's bias: issued here, complete at the drain behind the MFMAs (op.b is never null)
+        const float bcur = pvn_g(op.b)[n0 < op.nout ? n0 + n : 0];
+        const PvFwdOp nx = i + 1 < nops ? pvn_get_op<PvFwdOp>(ops_s, i + 1) : op;
+        if (i + 1 < nops) aim(nx);
+        else { nsrc = P; nstride = 0; nks = 1; }
         const int N = op.nout;
-        float pv[2][4];
-        if (op.kind == PVN_BIAS_ACT && n0 < N) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pv[t][r] = P[(16 * t + 4 * q + r) * N + n0 + n];
-        }
-        prefetch(i + 1);
         PVN_T(i * 8 + 1);
         if (op.kind == PVN_REPARAM) {
+            pvn_prefetch_plain<true>(wnext, nsrc, nstride, nks);
+            PVN_DRAIN_VMEM();
             // cur holds the heads output: cols [0,K) = z_mean, [K,2K) = z_log_var; nxt gets z (padded to Kz)
             if (tid < 32) {
                 const int b = tid;
@@ -233,14 +293,22 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
             }
         } else if (n0 < N) {
             f32x4 acc[2];
+            if (op.kind == PVN_BIAS_ACT) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[t][r] = op.kind == PVN_BIAS_ACT ? pv[t][r] : 0.f;
-            if (op.kind == PVN_DENSE) {
+                    for (int r = 0; r < 4; ++r) acc[t][r] = P[(16 * t + 4 * q + r) * N + n0 + n];
+                pvn_prefetch_plain<true>(wnext, nsrc, nstride, nks);
+                PVN_DRAIN_VMEM();
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
                 const int ks = op.kin >> 2;
                 const float* a0 = cur + n * PVN_LD + q * ks;
-                PVN_SWITCH(ks, pvn_mma<S_>(acc[0], acc[1], a0, a0 + 16 * PVN_LD, wcur));
+                PVN_SWITCH(ks, (pvn_mma<S_, true>(acc[0], acc[1], a0, a0 + 16 * PVN_LD, wcur, wnext, nsrc, nstride, nks)));
+                PVN_DRAIN_VMEM();
             }
 #ifdef PVN_TRACE
             asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]));
@@ -254,15 +322,19 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
                     const float x = acc[t][r] + bcur;
                     const float y = op.act == PV_ACT_ELU ? pv_elu(x) : x;
                     nxt[b * PVN_LD + n0 + n] = y;
-                    op.out[b * N + n0 + n] = y;
+                    pvn_g(op.out)[b * N + n0 + n] = y;
                 }
+        } else {
+            pvn_prefetch_plain<true>(wnext, nsrc, nstride, nks);
+            PVN_DRAIN_VMEM();
         }
         PVN_T(i * 8 + 3);
-        __syncthreads();  // nxt complete, every read of cur done
+        pvn_lds_barrier();  // nxt complete, every read of cur done
         PVN_T(i * 8 + 4);
         float* t_ = cur;
         cur = nxt;
         nxt = t_;
+        op = nx;
     }
 }
 
@@ -316,18 +388,20 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     PvW32 wnext;
 #pragma unroll
     for (int s = 0; s < 16; ++s) wnext.lo[s] = wnext.hi[s] = 0.f;
-    // B operands of op i: lane (k = n, q) of wave w reads W[16w + k][q * KS + s], KS = nout / 4
-    auto prefetch = [&](int i) {
-        if (i >= nops) return;
-        const PvBwdOp op = pvn_get_op<PvBwdOp>(ops_s, i);
-        if (op.kind != PVN_DENSE || n0 >= op.kin) return;
-        const int ks = op.nout >> 2;
-        const float* src = op.W + (n0 + n) * op.nout + q * ks;
-        PVN_SWITCH(ks, wnext = pvn_load_contig<S_>(wnext, src));
+    // B operands of op o: lane (k = n, q) of wave w reads the run W[16w + k][q * ks + s], s < ks = nout / 4
+    const float* nsrc = xch;
+    int nks = 4;
+    auto aim = [&](const PvBwdOp& o) {
+        nsrc = xch; nks = 4;
+        if (o.kind != PVN_DENSE || n0 >= o.kin) return;
+        nks = o.nout >> 2;
+        nsrc = o.W + (n0 + n) * o.nout + q * nks;
     };
-    prefetch(0);
+    PvBwdOp op = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, 0);
+    aim(op);
+    pvn_prefetch_plain<false>(wnext, nsrc, 0, nks);
+    PVN_DRAIN_VMEM();
     {   // dpre of the first op from the exchanged decoder feedback
-        const PvBwdOp op = pvn_get_op<PvBwdOp>(ops_s, 0);
         if (n0 < W0) {
             float xv[2][4], yv[2][4];
 #pragma unroll
@@ -336,7 +410,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                 for (int r = 0; r < 4; ++r) {
                     const int b = 16 * t + 4 * q + r;
                     xv[t][r] = xch[b * W0 + n0 + n];
-                    yv[t][r] = op.Y[b * W0 + n0 + n];
+                    yv[t][r] = pvn_g(op.Y)[b * W0 + n0 + n];
                 }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -346,38 +420,41 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                     float d = b < nrows ? xv[t][r] : 0.f;
                     if (op.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[t][r]);
                     cur[b * PVN_LD + n0 + n] = d;
-                    op.dpre[b * W0 + n0 + n] = d;
+                    pvn_g(op.dpre)[b * W0 + n0 + n] = d;
                 }
         }
     }
     __syncthreads();
 
     for (int i = 0; i < nops; ++i) {
-        const PvBwdOp op = pvn_get_op<PvBwdOp>(ops_s, i);
+        PVN_T(128 + i * 8 + 0);
         const PvW32 wb = wnext;
-        prefetch(i + 1);
         if (op.kind == PVN_FIRST_BIAS) {
             // cur = dpre1 (already in global memory for the wide encoder backward); b1 gets its Adam step here
-            const int N = op.nout;
+            const PvBwdOp fo = pvn_get_op<PvBwdOp>(ops_s, i);
+            const int N = fo.nout;
             if (tid < N) {
                 float g = 0.f;
 #pragma unroll 8
                 for (int b = 0; b < 32; ++b) g += cur[b * PVN_LD + tid];
                 if (MODE == PV_MODE_GRAD) {
-                    op.mB[tid] = st->acc ? op.mB[tid] + g : g;
+                    pvn_g(fo.mB)[tid] = st->acc ? pvn_g(fo.mB)[tid] + g : g;
                 } else {
-                    float w_ = op.B[tid], m_ = op.mB[tid], v_ = op.vB[tid];
-                    if (MODE == PV_MODE_TRAIN_ACC) g += op.gB[tid];
+                    float w_ = pvn_g(fo.B)[tid], m_ = pvn_g(fo.mB)[tid], v_ = pvn_g(fo.vB)[tid];
+                    if (MODE == PV_MODE_TRAIN_ACC) g += pvn_g(fo.gB)[tid];
                     pv_adam(w_, m_, v_, g, alpha, adam);
-                    op.B[tid] = w_;
-                    op.mB[tid] = m_;
-                    op.vB[tid] = v_;
+                    pvn_g(fo.B)[tid] = w_;
+                    pvn_g(fo.mB)[tid] = m_;
+                    pvn_g(fo.vB)[tid] = v_;
                 }
             }
             break;
         }
-        const PvBwdOp nx = pvn_get_op<PvBwdOp>(ops_s, i + 1);  // the table always ends with FIRST_BIAS
+        const PvBwdOp nx = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, i + 1);  // the table always ends with FIRST_BIAS
+        aim(nx);
         if (op.kind == PVN_REPARAM) {
+            pvn_prefetch_plain<false>(wnext, nsrc, 0, nks);
+            PVN_DRAIN_VMEM();
             // cur = dz [32][Kz]; result: dpre of the heads op [32][Kh] (cols [0,K) dmu, [K,2K) ds, rest 0)
             if (tid < 32) {
                 const int b = tid;
@@ -396,15 +473,15 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                 }
                 for (int k = 0; k < Kh; ++k) {
                     nxt[b * PVN_LD + k] = 0.f;
-                    nx.dpre[b * Kh + k] = 0.f;
+                    pvn_g(nx.dpre)[b * Kh + k] = 0.f;
                 }
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
                     if (k < K) {
                         nxt[b * PVN_LD + k] = dmu[k];
                         nxt[b * PVN_LD + K + k] = dsv[k];
-                        nx.dpre[b * Kh + k] = dmu[k];
-                        nx.dpre[b * Kh + K + k] = dsv[k];
+                        pvn_g(nx.dpre)[b * Kh + k] = dmu[k];
+                        pvn_g(nx.dpre)[b * Kh + K + k] = dsv[k];
                     }
             }
         } else if (n0 < op.kin) {
@@ -415,7 +492,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) yv[t][r] = nx.Y[(16 * t + 4 * q + r) * Kin + n0 + n];
+                    for (int r = 0; r < 4; ++r) yv[t][r] = pvn_g(nx.Y)[(16 * t + 4 * q + r) * Kin + n0 + n];
             }
             f32x4 acc[2];
 #pragma unroll
@@ -423,7 +500,14 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
             const float* a0 = cur + n * PVN_LD + q * ks;
-            PVN_SWITCH(ks, pvn_mma<S_>(acc[0], acc[1], a0, a0 + 16 * PVN_LD, wb));
+            PVN_T(128 + i * 8 + 1);
+            PVN_SWITCH(ks, (pvn_mma<S_, false>(acc[0], acc[1], a0, a0 + 16 * PVN_LD, wb, wnext, nsrc, 0, nks)));
+#ifdef PVN_TRACE
+            asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]));
+            PVN_T(128 + i * 8 + 5);
+#endif
+            PVN_DRAIN_VMEM();
+            PVN_T(128 + i * 8 + 2);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -433,15 +517,21 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                     if (to_dpre) {
                         if (nx.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[t][r]);
                         if (b >= nrows) d = 0.f;
-                        nx.dpre[b * Kin + n0 + n] = d;
+                        pvn_g(nx.dpre)[b * Kin + n0 + n] = d;
                     }
                     nxt[b * PVN_LD + n0 + n] = d;
                 }
+        } else {
+            pvn_prefetch_plain<false>(wnext, nsrc, 0, nks);
+            PVN_DRAIN_VMEM();
         }
-        __syncthreads();
+        PVN_T(128 + i * 8 + 3);
+        pvn_lds_barrier();
+        PVN_T(128 + i * 8 + 4);
         float* t_ = cur;
         cur = nxt;
         nxt = t_;
+        op = nx;
     }
 }
 
