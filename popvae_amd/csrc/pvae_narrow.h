@@ -133,10 +133,11 @@ struct PvW32 {
 // iterations): issued in one burst ahead of the MFMAs, 8 waves x 32 loads queue up in the CU's one address unit for
 // ~1 us before the first MFMA can issue.  The chunk index is clamped to the next op's own operand count (re-loading
 // its last chunk) so that no load sits under a condition; a wave with nothing to prefetch passes nks = 1, stride 0
-// and any valid address.  FWD: element s at nsrc[s * nstride]; else the contiguous run nsrc[s].
+// and any valid address.  FWD: element s at nbase[nlane + s * nstride]; else the contiguous run nbase[nlane + s].
+// nbase / nstride / nks are wave-uniform (SGPRs), so the per-load address arithmetic is scalar; nlane is the lane's part.
 template <int KS, bool FWD>
 __device__ __forceinline__ void pvn_mma(f32x4& acc0, f32x4& acc1, const float* a0, const float* a1, const PvW32& w,
-                                        PvW32& wn, const float* nsrc, int nstride, int nks) {
+                                        PvW32& wn, const float* nbase, int nlane, int nstride, int nks) {
     constexpr int NI = KS / 4;
     f32x4 x0[NI], x1[NI];
 #pragma unroll
@@ -153,10 +154,10 @@ __device__ __forceinline__ void pvn_mma(f32x4& acc0, f32x4& acc1, const float* a
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int sc = min(4 * c + e, nks - 1);
-                    PVN_WSET(wn, 4 * c + e, pvn_g(nsrc)[sc * nstride]);
+                    PVN_WSET(wn, 4 * c + e, pvn_g(nbase + sc * nstride)[nlane]);
                 }
             } else {
-                const f32x4 v = pvn_g4(nsrc)[min(c, (nks >> 2) - 1)];
+                const f32x4 v = pvn_g4(nbase + 4 * min(c, (nks >> 2) - 1))[nlane >> 2];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) PVN_WSET(wn, 4 * c + e, v[e]);
             }
@@ -171,14 +172,14 @@ __device__ __forceinline__ void pvn_mma(f32x4& acc0, f32x4& acc1, const float* a
 }
 // the same 8 chunks without a layer to hide behind (first op, ops without MFMAs)
 template <bool FWD>
-__device__ __forceinline__ void pvn_prefetch_plain(PvW32& wn, const float* nsrc, int nstride, int nks) {
+__device__ __forceinline__ void pvn_prefetch_plain(PvW32& wn, const float* nbase, int nlane, int nstride, int nks) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         if (FWD) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) PVN_WSET(wn, 4 * c + e, pvn_g(nsrc)[min(4 * c + e, nks - 1) * nstride]);
+            for (int e = 0; e < 4; ++e) PVN_WSET(wn, 4 * c + e, pvn_g(nbase + min(4 * c + e, nks - 1) * nstride)[nlane]);
         } else {
-            const f32x4 v = pvn_g4(nsrc)[min(c, (nks >> 2) - 1)];
+            const f32x4 v = pvn_g4(nbase + 4 * min(c, (nks >> 2) - 1))[nlane >> 2];
 #pragma unroll
             for (int e = 0; e < 4; ++e) PVN_WSET(wn, 4 * c + e, v[e]);
         }
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
     float* cur = smem;                   // [32][PVN_LD]
     float* nxt = smem + 32 * PVN_LD;     // [32][PVN_LD]
     int* ops_s = reinterpret_cast<int*>(smem + 2 * 32 * PVN_LD);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, q = lane >> 4;
     const int n0 = wave * 16;
     if (blockIdx.x != 0) {
         const int p = (int)(blockIdx.x >> 3) - 1;
@@ -235,14 +236,16 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
     for (int s = 0; s < 16; ++s) wnext.lo[s] = wnext.hi[s] = 0.f;
     // where this lane's B operands of op `o` start (element s at src[s * stride], s < ks); a wave that has
     // nothing to load for `o` gets a harmless address
-    const float* nsrc = P;
+    const float* nbase = P;
+    int nlane = 0;
     int nstride = 0, nks = 1;
     auto aim = [&](const PvFwdOp& o) {
-        nsrc = P; nstride = 0; nks = 1;
+        nbase = P; nlane = 0; nstride = 0; nks = 1;
         if (o.kind != PVN_DENSE || n0 >= o.nout) return;
         nks = o.kin >> 2;
         nstride = o.nout;
-        nsrc = o.W + (q * nks) * o.nout + n0 + n;
+        nbase = o.W;
+        nlane = (q * nks) * o.nout + n0 + n;
     };
     if (op0 > 0) {  // decoder.predict: start behind REPARAM with z (already in z_out) as the activation
         if (tid < 32)
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
     }
     PvFwdOp op = pvn_get_op<PvFwdOp>(ops_s, op0);
     aim(op);
-    pvn_prefetch_plain<true>(wnext, nsrc, nstride, nks);
+    pvn_prefetch_plain<true>(wnext, nbase, nlane, nstride, nks);
     PVN_DRAIN_VMEM();
     for (int i = op0; i < nops; ++i) {
         PVN_T(i * 8 + 0);
@@ -260,11 +263,11 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
         const float bcur = pvn_g(op.b)[n0 < op.nout ? n0 + n : 0];
         const PvFwdOp nx = i + 1 < nops ? pvn_get_op<PvFwdOp>(ops_s, i + 1) : op;
         if (i + 1 < nops) aim(nx);
-        else { nsrc = P; nstride = 0; nks = 1; }
+        else { nbase = P; nlane = 0; nstride = 0; nks = 1; }
         const int N = op.nout;
         PVN_T(i * 8 + 1);
         if (op.kind == PVN_REPARAM) {
-            pvn_prefetch_plain<true>(wnext, nsrc, nstride, nks);
+            pvn_prefetch_plain<true>(wnext, nbase, nlane, nstride, nks);
             PVN_DRAIN_VMEM();
             // cur holds the heads output: cols [0,K) = z_mean, [K,2K) = z_log_var; nxt gets z (padded to Kz)
             if (tid < 32) {
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[t][r] = P[(16 * t + 4 * q + r) * N + n0 + n];
-                pvn_prefetch_plain<true>(wnext, nsrc, nstride, nks);
+                pvn_prefetch_plain<true>(wnext, nbase, nlane, nstride, nks);
                 PVN_DRAIN_VMEM();
             } else {
 #pragma unroll
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
                     for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
                 const int ks = op.kin >> 2;
                 const float* a0 = cur + n * PVN_LD + q * ks;
-                PVN_SWITCH(ks, (pvn_mma<S_, true>(acc[0], acc[1], a0, a0 + 16 * PVN_LD, wcur, wnext, nsrc, nstride, nks)));
+                PVN_SWITCH(ks, (pvn_mma<S_, true>(acc[0], acc[1], a0, a0 + 16 * PVN_LD, wcur, wnext, nbase, nlane, nstride, nks)));
                 PVN_DRAIN_VMEM();
             }
 #ifdef PVN_TRACE
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
                     pvn_g(op.out)[b * N + n0 + n] = y;
                 }
         } else {
-            pvn_prefetch_plain<true>(wnext, nsrc, nstride, nks);
+            pvn_prefetch_plain<true>(wnext, nbase, nlane, nstride, nks);
             PVN_DRAIN_VMEM();
         }
         PVN_T(i * 8 + 3);
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     float* cur = smem;
     float* nxt = smem + 32 * PVN_LD;
     int* ops_s = reinterpret_cast<int*>(smem + 2 * 32 * PVN_LD);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, q = lane >> 4;
     const int n0 = wave * 16;
     if (blockIdx.x != 0) {
         const int p = (int)(blockIdx.x >> 3) - 1;
@@ -389,17 +392,19 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
 #pragma unroll
     for (int s = 0; s < 16; ++s) wnext.lo[s] = wnext.hi[s] = 0.f;
     // B operands of op o: lane (k = n, q) of wave w reads the run W[16w + k][q * ks + s], s < ks = nout / 4
-    const float* nsrc = xch;
+    const float* nbase = xch;
+    int nlane = 0;
     int nks = 4;
     auto aim = [&](const PvBwdOp& o) {
-        nsrc = xch; nks = 4;
+        nbase = xch; nlane = 0; nks = 4;
         if (o.kind != PVN_DENSE || n0 >= o.kin) return;
         nks = o.nout >> 2;
-        nsrc = o.W + (n0 + n) * o.nout + q * nks;
+        nbase = o.W;
+        nlane = (n0 + n) * o.nout + q * nks;
     };
     PvBwdOp op = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, 0);
     aim(op);
-    pvn_prefetch_plain<false>(wnext, nsrc, 0, nks);
+    pvn_prefetch_plain<false>(wnext, nbase, nlane, 0, nks);
     PVN_DRAIN_VMEM();
     {   // dpre of the first op from the exchanged decoder feedback
         if (n0 < W0) {
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
         const PvBwdOp nx = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, i + 1);  // the table always ends with FIRST_BIAS
         aim(nx);
         if (op.kind == PVN_REPARAM) {
-            pvn_prefetch_plain<false>(wnext, nsrc, 0, nks);
+            pvn_prefetch_plain<false>(wnext, nbase, nlane, 0, nks);
             PVN_DRAIN_VMEM();
             // cur = dz [32][Kz]; result: dpre of the heads op [32][Kh] (cols [0,K) dmu, [K,2K) ds, rest 0)
             if (tid < 32) {
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                 for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
             const float* a0 = cur + n * PVN_LD + q * ks;
             PVN_T(128 + i * 8 + 1);
-            PVN_SWITCH(ks, (pvn_mma<S_, false>(acc[0], acc[1], a0, a0 + 16 * PVN_LD, wb, wnext, nsrc, 0, nks)));
+            PVN_SWITCH(ks, (pvn_mma<S_, false>(acc[0], acc[1], a0, a0 + 16 * PVN_LD, wb, wnext, nbase, nlane, 0, nks)));
 #ifdef PVN_TRACE
             asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]));
             PVN_T(128 + i * 8 + 5);
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                     nxt[b * PVN_LD + n0 + n] = d;
                 }
         } else {
-            pvn_prefetch_plain<false>(wnext, nsrc, 0, nks);
+            pvn_prefetch_plain<false>(wnext, nbase, nlane, 0, nks);
             PVN_DRAIN_VMEM();
         }
         PVN_T(128 + i * 8 + 3);
