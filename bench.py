@@ -156,8 +156,8 @@ def main():
             # C-side loop: exactly len(rows2d) train steps, no validation rows
             losses.append(eng.train_epoch(rows2d.reshape(-1), np.zeros(0, np.int32))[0])
         else:
-            for r in rows2d[:-1]:
-                step_engine._step(r, None, E.MODE_TRAIN, want_loss=False)
+            for k in range(len(rows2d) - 1):  # the next batch is known: its first-layer forward rides on this step
+                step_engine._step(rows2d[k], None, E.MODE_TRAIN, want_loss=False, next_rows=rows2d[k + 1])
             losses.append(step_engine._step(rows2d[-1], None, E.MODE_TRAIN, want_loss=True)[0])
 
     def barrier():

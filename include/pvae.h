@@ -126,6 +126,12 @@ int pvae_exchange_copy(pvae_engine* e, int which, float* host, int64_t n_floats,
 int pvae_stage_a(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, int mode);
 int pvae_stage_b(pvae_engine* e, int mode);
 int pvae_stage_c(pvae_engine* e, int mode, float* out3);
+/* stage C of a TRAIN step that also knows the next batch: the wide encoder backward, which has every updated first-layer
+ * tile in registers anyway, forms the next batch's partial first-layer sums on the way (as pvae_train_epoch does between
+ * its steps), so that the next pvae_stage_a -- if it is called with exactly these rows -- only gathers and reduces and
+ * the first-layer kernel is read once per step instead of twice.  Any other call in between drops the promise (the
+ * next stage A then runs the ordinary forward).  Other modes, or next_rows == NULL: same as pvae_stage_c. */
+int pvae_stage_c_next(pvae_engine* e, int mode, float* out3, const int32_t* next_rows, int32_t next_n);
 int pvae_stage_encode(pvae_engine* e, int32_t n, float* z_mean, float* z_log_var, float* z);
 
 /* measurement hook: average device time (ms) of the last call's kernels by name, via hipEvents on the

@@ -105,6 +105,8 @@ struct pvae_engine {
     int64_t loss_cap = 0;
     float lr_host = 1e-3f;
     bool has_best = false;
+    // staged API: rows whose first-layer partial sums the last pvae_stage_c_next left in encpart (empty = none)
+    std::vector<int32_t> promised_rows;
     // pinned host staging ring for the per-step API (rows + eps), so that async copies never read caller memory
     struct Slot { char* host = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
     Slot slots[8];
@@ -658,7 +660,7 @@ int begin_batch(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
                                       "pvae_train_epoch, which tile them", n);
     if (!e->geno) return set_err(e, -3, "no genotypes loaded (pvae_load_genotypes)");
     if ((rc = check_rows(e, rows, n))) return rc;
-    if ((rc = ensure_rows(e, n))) return rc;
+    if ((rc = ensure_rows(e, 64))) return rc;
     pvae_engine::Slot& sl = e->slots[e->slot_next];
     e->slot_next = (e->slot_next + 1) % 8;
     if (!sl.host) {
@@ -708,6 +710,7 @@ int run_tile(pvae_engine* e, int row_offset, int nrows, int n_batch, int tile, i
 }
 
 int full_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3, int mode) {
+    e->promised_rows.clear();
     int rc;
     if (e->cfg.world != 1)
         return set_err(e, -5, "world > 1: drive the step through pvae_stage_a/b/c with all-reduces in between");
@@ -745,6 +748,7 @@ int full_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, 
 float* pick(Buf3& b, int which) { return which == 0 ? b.w : which == 1 ? b.m : which == 2 ? b.v : b.g; }
 
 int tensor_io(pvae_engine* e, int index, int which, float* host, int64_t count, bool to_device) {
+    if (to_device) e->promised_rows.clear();
     if (index < 0 || index >= (int)e->tensors.size()) return set_err(e, -2, "tensor index %d out of range", index);
     const TensorRef& t = e->tensors[index];
     const int64_t expect = t.cols ? t.rows * t.cols : t.rows;
@@ -1022,6 +1026,7 @@ int pvae_synchronize(pvae_engine* e) {
 }
 
 int pvae_load_genotypes(pvae_engine* e, const uint8_t* packed, int64_t n_samples, int64_t row_bytes) {
+    e->promised_rows.clear();
     if (row_bytes < e->Lp / 4 || row_bytes % 8) return set_err(e, -2, "row_bytes %lld: need a multiple of 8 >= %lld", (long long)row_bytes, (long long)(e->Lp / 4));
     if (n_samples <= 0) return set_err(e, -2, "no samples");
     // reject the reserved "missing" code 3: the reference imputes before training (popvae.py:231-235)
@@ -1074,6 +1079,7 @@ int pvae_reset_optimizer(pvae_engine* e) {
 }
 
 int pvae_init_weights(pvae_engine* e, uint64_t seed) {
+    e->promised_rows.clear();
     int rc;
     std::vector<float> buf;
     for (int ti = 0; ti < (int)e->tensors.size(); ++ti) {
@@ -1122,6 +1128,7 @@ int pvae_grad_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* 
 
 int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const int32_t* val_rows, int32_t n_val,
                      float* loss, float* val_loss) {
+    e->promised_rows.clear();
     int rc;
     if (e->cfg.world != 1) return set_err(e, -5, "world > 1: use the staged API");
     if (!e->geno) return set_err(e, -3, "no genotypes loaded (pvae_load_genotypes)");
@@ -1212,6 +1219,7 @@ int pvae_stage_encode(pvae_engine* e, int32_t n, float* z_mean, float* z_log_var
 
 int pvae_encode(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* z_mean, float* z_log_var,
                 float* z) {
+    e->promised_rows.clear();
     int rc;
     if (e->cfg.world != 1) return set_err(e, -5, "world > 1: use pvae_stage_a + all-reduce + pvae_stage_encode");
     const int B = 32;
@@ -1328,6 +1336,7 @@ int pvae_snapshot_best(pvae_engine* e) {
 }
 
 int pvae_restore_best(pvae_engine* e) {
+    e->promised_rows.clear();
     if (!e->has_best) return set_err(e, -6, "no snapshot taken");
     int rc = 0;
     for_each_buf(e, [&](Buf3& b) {
@@ -1367,13 +1376,40 @@ int pvae_stage_a(pvae_engine* e, const int32_t* rows, int32_t n, const float* ep
         rc = begin_batch(e, rows, n, eps, mode == 0);
     }
     if (rc) return rc;
-    return stage_a(e, 0, mode != 3);
+    // the previous pvae_stage_c_next already formed this batch's partial first-layer sums on the updated weights
+    const bool fwd_done = !e->promised_rows.empty() && (int32_t)e->promised_rows.size() == n &&
+                          !memcmp(e->promised_rows.data(), rows, (size_t)n * sizeof(int32_t));
+    e->promised_rows.clear();
+    return stage_a(e, 0, mode != 3, fwd_done);
 }
 int pvae_stage_b(pvae_engine* e, int mode) { return stage_b(e, mode); }
 int pvae_stage_c(pvae_engine* e, int mode, float* out3) {
     int rc;
+    e->promised_rows.clear();
     if ((rc = ensure_loss(e, 1))) return rc;
     if ((rc = stage_c(e, mode, e->d_loss))) return rc;
+    return fetch_out3(e, out3);
+}
+int pvae_stage_c_next(pvae_engine* e, int mode, float* out3, const int32_t* next_rows, int32_t next_n) {
+    int rc;
+    e->promised_rows.clear();
+    if (mode != 0 || !e->fuse_fwd || !next_rows || next_n <= 0) return pvae_stage_c(e, mode, out3);
+    if (next_n > 32) return set_err(e, -2, "a device pass takes at most 32 rows (got %d)", next_n);
+    if ((rc = check_rows(e, next_rows, next_n))) return rc;
+    if ((rc = ensure_loss(e, 1))) return rc;
+    pvae_engine::Slot& sl = e->slots[e->slot_next];
+    e->slot_next = (e->slot_next + 1) % 8;
+    if (!sl.host) {
+        HIPCHK(hipHostMalloc((void**)&sl.host, kSlotBytes, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    }
+    if (sl.pending) HIPCHK(hipEventSynchronize(sl.ev));
+    memcpy(sl.host, next_rows, (size_t)next_n * sizeof(int));
+    HIPCHK(hipMemcpyAsync(e->d_rows + 32, sl.host, (size_t)next_n * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipEventRecord(sl.ev, e->stream));
+    sl.pending = true;
+    if ((rc = stage_c(e, 0, e->d_loss, true, 32, next_n))) return rc;
+    e->promised_rows.assign(next_rows, next_rows + next_n);
     return fetch_out3(e, out3);
 }
 

@@ -77,6 +77,11 @@ class ShardedEngine:
                                   n_snps_global=self.n_snps_global, snp_offset=self.lo, rank=self.rank,
                                   world=self.world, **adam)
         self._bufs = [self._wrap(*self.eng.exchange_buffer(i), device_id) for i in (0, 1)]
+        try:  # test doubles (CPU stand-in engines) take no next_rows
+            import inspect
+            self._can_fuse = "next_rows" in inspect.signature(self.eng.stage_c).parameters
+        except (TypeError, ValueError):
+            self._can_fuse = False
         if hasattr(self.eng, "set_stream") and torch.cuda.is_available():
             self.eng.set_stream(torch.cuda.current_stream().cuda_stream)
 
@@ -126,11 +131,15 @@ class ShardedEngine:
         self.eng.restore_best()
 
     # -- steps ---------------------------------------------------------------------------------
-    def _step(self, rows, eps, mode, want_loss=True):
+    def _step(self, rows, eps, mode, want_loss=True, next_rows=None):
+        """``next_rows`` (train steps): the batch of the NEXT call, so that its first-layer forward rides on this
+        step's wide encoder backward; the partial sums it leaves are all-reduced by the next call as usual."""
         self.eng.stage_a(rows, eps, mode)
         self._allreduce(0)
         self.eng.stage_b(mode)
         self._allreduce(1)
+        if next_rows is not None and mode == MODE_TRAIN and self._can_fuse:
+            return self.eng.stage_c(mode, want_loss, next_rows=next_rows)
         return self.eng.stage_c(mode, want_loss)
 
     def _eps(self, n, eps):
@@ -139,8 +148,8 @@ class ShardedEngine:
         give identical draws on all ranks, with no communication."""
         return eps
 
-    def train_step(self, rows, eps=None, want_loss=True):
-        return self._step(rows, self._eps(len(rows), eps), MODE_TRAIN, want_loss)
+    def train_step(self, rows, eps=None, want_loss=True, next_rows=None):
+        return self._step(rows, self._eps(len(rows), eps), MODE_TRAIN, want_loss, next_rows)
 
     def eval_step(self, rows, eps=None, want_loss=True):
         return self._step(rows, self._eps(len(rows), eps), MODE_EVAL, want_loss)
@@ -184,9 +193,12 @@ class ShardedEngine:
         perm = np.ascontiguousarray(perm, dtype=np.int32)
         val_rows = np.ascontiguousarray(val_rows, dtype=np.int32)
         tl, vl = [], []
+        fuse = B <= 32
         for i0 in range(0, len(perm), B):
             r = perm[i0:i0 + B]
-            tl.append(self.train_step(r, None if eps_fn is None else eps_fn(len(r)))[0])
+            nxt = perm[i0 + B:i0 + 2 * B] if i0 + B < len(perm) else val_rows[:B]
+            tl.append(self.train_step(r, None if eps_fn is None else eps_fn(len(r)),
+                                      next_rows=nxt if fuse and len(nxt) else None)[0])
         for i0 in range(0, len(val_rows), B):
             r = val_rows[i0:i0 + B]
             vl.append(self.eval_step(r, None if eps_fn is None else eps_fn(len(r)))[0])

@@ -20,7 +20,7 @@ ENGINE_SYMBOLS = [
     "pvae_get_tensor", "pvae_init_weights", "pvae_get_moment", "pvae_reset_optimizer", "pvae_set_lr", "pvae_get_lr",
     "pvae_train_step", "pvae_eval_step", "pvae_grad_step", "pvae_get_grad", "pvae_train_epoch", "pvae_encode",
     "pvae_decode", "pvae_pca_gram", "pvae_snapshot_best", "pvae_restore_best", "pvae_exchange_buffer", "pvae_exchange_copy", "pvae_stage_a", "pvae_stage_b",
-    "pvae_stage_c", "pvae_stage_encode", "pvae_set_timing", "pvae_get_timing",
+    "pvae_stage_c", "pvae_stage_c_next", "pvae_stage_encode", "pvae_set_timing", "pvae_get_timing",
 ]
 
 
@@ -80,6 +80,7 @@ def lib():
         L.pvae_stage_a.argtypes = [vp, _i32p, i32, _fopt, C.c_int]
         L.pvae_stage_b.argtypes = [vp, C.c_int]
         L.pvae_stage_c.argtypes = [vp, C.c_int, _fopt]
+        L.pvae_stage_c_next.argtypes = [vp, C.c_int, _fopt, C.POINTER(C.c_int32), i32]
         L.pvae_stage_encode.argtypes = [vp, i32, _fopt, _fopt, _fopt]
         L.pvae_set_timing.argtypes = [vp, C.c_int]
         L.pvae_get_timing.argtypes = [vp, C.c_char_p, _fopt, C.POINTER(i64)]
@@ -290,8 +291,15 @@ class Engine:
     def stage_b(self, mode):
         self._ck(lib().pvae_stage_b(self._h, mode))
 
-    def stage_c(self, mode, want_loss=True):
-        self._ck(lib().pvae_stage_c(self._h, mode, _fptr(self._out3) if want_loss else None))
+    def stage_c(self, mode, want_loss=True, next_rows=None):
+        """``next_rows``: the next batch, if known (train steps): its first-layer forward then rides on this step's wide
+        encoder backward (pvae_stage_c_next)."""
+        out = _fptr(self._out3) if want_loss else None
+        if next_rows is None:
+            self._ck(lib().pvae_stage_c(self._h, mode, out))
+        else:
+            nr = np.ascontiguousarray(next_rows, dtype=np.int32)
+            self._ck(lib().pvae_stage_c_next(self._h, mode, out, nr.ctypes.data_as(C.POINTER(C.c_int32)), len(nr)))
         return tuple(float(x) for x in self._out3) if want_loss else None
 
     def stage_encode(self, n):

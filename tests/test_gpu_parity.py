@@ -295,3 +295,37 @@ def test_errors_are_loud():
     with pytest.raises(RuntimeError):
         e.load_genotypes(bad)                         # reserved 'missing' code
     e.close()
+
+
+def test_staged_step_with_promised_next_batch():
+    """pvae_stage_c_next (the next batch's first-layer forward rides on the wide encoder backward) against the plain
+    staged sequence: same losses, same weights; a broken promise (other rows, or a call in between) falls back."""
+    N, L, W, D, K = 90, 2500, 128, 3, 2
+    dc, w = _problem(N, L, W, D, K, seed=21)
+    g = np.random.default_rng(6)
+    batches = [g.choice(N, n, replace=False).astype(np.int32) for n in (32, 32, 17, 32, 32)]
+    epss = [g.normal(size=(len(b), K)).astype(np.float32) for b in batches]
+
+    def run(promise):
+        e = _mk(dc, w, W, D, K)
+        e.lr = 1e-3
+        out = []
+        for k, (b, ep) in enumerate(zip(batches, epss)):
+            e.stage_a(b, ep, engine.MODE_TRAIN)
+            e.stage_b(engine.MODE_TRAIN)
+            nxt = None
+            if promise and k + 1 < len(batches):
+                # step 2 promises the WRONG rows, step 3 keeps its promise but an encode call intervenes
+                nxt = batches[k + 1] if k != 2 else batches[0]
+            out.append(e.stage_c(engine.MODE_TRAIN, True, next_rows=nxt)[0])
+            if promise and k == 3:
+                e.encode(np.arange(5, dtype=np.int32))
+        wts = e.get_weights()
+        e.close()
+        return out, wts
+
+    la, wa = run(False)
+    lb, wb = run(True)
+    assert np.allclose(la, lb, rtol=1e-6), (la, lb)
+    for i, (a, b) in enumerate(zip(wa, wb)):
+        assert np.abs(a - b).max() <= 1e-6, (i, np.abs(a - b).max())
