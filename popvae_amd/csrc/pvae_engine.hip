@@ -382,7 +382,7 @@ int build_bwd_ops(pvae_engine* e, bool grad, PvBwdOp** out) {
     PvBwdOp f{};
     f.kind = PVN_FIRST_BIAS; f.dpre = e->dpre1; f.B = e->b1.w; f.mB = grad ? e->b1.g : e->b1.m; f.vB = grad ? nullptr : e->b1.v;
     f.gB = e->b1.g;
-    f.Y = e->h[0]; f.nout = e->Wp; f.kin = 0; f.act = PV_ACT_ELU;
+    f.Y = e->h[0]; f.nout = e->Wp; f.kin = e->fused_narrow ? 1 : 0 /* 1: pvk_narrow_adam updates b1 */; f.act = PV_ACT_ELU;
     ops.push_back(f);
     e->n_bwd_ops = (int)ops.size();
     for (auto p : e->dpre_bufs)
@@ -413,7 +413,7 @@ int build_fwd_ops(pvae_engine* e) {
 
 int narrow_fused_fwd(pvae_engine* e, bool encoder_only, bool decoder_only = false) {
     const int nops = encoder_only ? e->n_enc_ops : e->n_fwd_ops;
-    hipLaunchKernelGGL(pvk_narrow_fwd, dim3(e->narrow_warm ? 8 * (nops + 1) : 1), dim3(PVN_THREADS), pvn_lds_fwd(), e->stream,
+    hipLaunchKernelGGL(pvk_narrow_fwd, dim3(e->narrow_warm ? 8 * (nops + 1) : PVN_WORKERS), dim3(PVN_THREADS), pvn_lds_fwd(), e->stream,
                        e->d_fwd_ops, decoder_only ? e->n_enc_ops : 0, nops, e->P, e->eps, e->K, e->Kz, e->z, e->kl);
     return launch_check(e, "narrow_fwd");
 }
@@ -560,7 +560,7 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
     if (e->fused_narrow) {
         {
         Timer t(e, C_NARROW_BWD);
-        const dim3 chain_grid(e->narrow_warm && mode != 1 ? 8 * (e->n_bwd_ops + 1) : 1);
+        const dim3 chain_grid(mode == 1 ? 1 : e->narrow_warm ? 8 * (e->n_bwd_ops + 1) : PVN_WORKERS);
 #define PV_NARROW_BWD(MD)                                                                                                      \
     hipLaunchKernelGGL(pvk_narrow_bwd<MD>, chain_grid, dim3(PVN_THREADS), pvn_lds_bwd(), e->stream, table, e->n_bwd_ops, e->xch1, \
                        e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st, e->adam, d_out3, mode == 1 ? 0 : 1)

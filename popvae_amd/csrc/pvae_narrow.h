@@ -14,6 +14,11 @@
 #include "pvae_kernels.h"
 
 #define PVN_LD 132
+// The batch's 32 rows are independent through the whole chain, so the chain runs as PVN_WORKERS workgroups on as many
+// CUs, each with PVN_NT 16-row tiles: half the MFMAs per layer on each CU's matrix pipe, no communication at all.
+#define PVN_NT 1
+#define PVN_WORKERS (2 / PVN_NT)
+#define PVN_ROWS (16 * PVN_NT)
 #define PVN_THREADS 512
 
 enum { PVN_DENSE = 0, PVN_BIAS_ACT = 1, PVN_REPARAM = 2, PVN_FIRST_BIAS = 3 };
@@ -136,14 +141,16 @@ struct PvW32 {
 // and any valid address.  FWD: element s at nbase[nlane + s * nstride]; else the contiguous run nbase[nlane + s].
 // nbase / nstride / nks are wave-uniform (SGPRs), so the per-load address arithmetic is scalar; nlane is the lane's part.
 template <int KS, bool FWD>
-__device__ __forceinline__ void pvn_mma(f32x4& acc0, f32x4& acc1, const float* a0, const float* a1, const PvW32& w,
-                                        PvW32& wn, const float* nbase, int nlane, int nstride, int nks) {
+__device__ __forceinline__ void pvn_mma(f32x4 (&acc)[2], const float* a0, const PvW32& w, PvW32& wn, const float* nbase,
+                                        int nlane, int nstride, int nks) {
+    // acc[0], acc[1]: the two row tiles (PVN_NT == 2), or the even-k / odd-k partial sums of the one tile (PVN_NT == 1:
+    // two chains keep dependent MFMAs 2 apart; the caller adds them)
     constexpr int NI = KS / 4;
-    f32x4 x0[NI], x1[NI];
+    f32x4 x0[NI], x1[PVN_NT == 2 ? NI : 1];
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
         x0[q] = *reinterpret_cast<const f32x4*>(a0 + 4 * q);
-        x1[q] = *reinterpret_cast<const f32x4*>(a1 + 4 * q);
+        if (PVN_NT == 2) x1[q] = *reinterpret_cast<const f32x4*>(a0 + 16 * PVN_LD + 4 * q);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -164,11 +171,16 @@ __device__ __forceinline__ void pvn_mma(f32x4& acc0, f32x4& acc1, const float* a
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[q][e], PVN_W(w, 4 * q + e), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[q][e], PVN_W(w, 4 * q + e), acc1, 0, 0, 0);
+            if (PVN_NT == 2) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[q][e], PVN_W(w, 4 * q + e), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[PVN_NT == 2 ? q : 0][e], PVN_W(w, 4 * q + e), acc[1], 0, 0, 0);
+            } else {
+                acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[q][e], PVN_W(w, 4 * q + e), acc[e & 1], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (PVN_NT == 1) acc[0] += acc[1];
 }
 // the same 8 chunks without a layer to hide behind (first op, ops without MFMAs)
 template <bool FWD>
@@ -215,14 +227,16 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
                                                               const float* __restrict__ eps, int K, int Kz,
                                                               float* __restrict__ z_out, float* __restrict__ kl_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* cur = smem;                   // [32][PVN_LD]
-    float* nxt = smem + 32 * PVN_LD;     // [32][PVN_LD]
+    float* cur = smem;                   // [PVN_ROWS][PVN_LD] of the [32][PVN_LD] reserved
+    float* nxt = smem + 32 * PVN_LD;
     int* ops_s = reinterpret_cast<int*>(smem + 2 * 32 * PVN_LD);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, q = lane >> 4;
     const int n0 = wave * 16;
-    if (blockIdx.x != 0) {
+    const int rb = PVN_ROWS * (int)blockIdx.x;  // first batch row of this worker
+    if (blockIdx.x >= PVN_WORKERS) {
+        // warm-up role: block 8 (p + 1) + w shares (by the dispatcher's round-robin placement) the XCD of worker w
         const int p = (int)(blockIdx.x >> 3) - 1;
-        if ((blockIdx.x & 7) == 0 && p < nops) {
+        if ((int)(blockIdx.x & 7) < PVN_WORKERS && p >= 0 && p < nops) {
             const PvFwdOp op = ops[p];
             if (op.kind == PVN_DENSE) pvn_warm_l2(op.W, op.kin * op.nout, tid);
         }
@@ -248,8 +262,8 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
         nlane = (q * nks) * o.nout + n0 + n;
     };
     if (op0 > 0) {  // decoder.predict: start behind REPARAM with z (already in z_out) as the activation
-        if (tid < 32)
-            for (int k = 0; k < Kz; ++k) cur[tid * PVN_LD + k] = z_out[tid * Kz + k];
+        if (tid < PVN_ROWS)
+            for (int k = 0; k < Kz; ++k) cur[tid * PVN_LD + k] = z_out[(rb + tid) * Kz + k];
         __syncthreads();
     }
     PvFwdOp op = pvn_get_op<PvFwdOp>(ops_s, op0);
@@ -270,17 +284,17 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
             pvn_prefetch_plain<true>(wnext, nbase, nlane, nstride, nks);
             PVN_DRAIN_VMEM();
             // cur holds the heads output: cols [0,K) = z_mean, [K,2K) = z_log_var; nxt gets z (padded to Kz)
-            if (tid < 32) {
-                const int b = tid;
+            if (tid < PVN_ROWS) {
+                const int lr = tid, b = rb + tid;  // row in LDS, row of the batch
                 float mu[16], sv[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    mu[k] = k < K ? cur[b * PVN_LD + k] : 0.f;
-                    sv[k] = k < K ? cur[b * PVN_LD + K + k] : 0.f;
+                    mu[k] = k < K ? cur[lr * PVN_LD + k] : 0.f;
+                    sv[k] = k < K ? cur[lr * PVN_LD + K + k] : 0.f;
                 }
                 float acc = 0.f;
                 for (int k = 0; k < Kz; ++k) {
-                    nxt[b * PVN_LD + k] = 0.f;
+                    nxt[lr * PVN_LD + k] = 0.f;
                     z_out[b * Kz + k] = 0.f;
                 }
 #pragma unroll
@@ -289,28 +303,28 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
                         const float es = expf(sv[k]);
                         const float zz = mu[k] + es * eps[b * K + k];  // exp(s), not exp(s/2): popvae.py:389
                         acc += 1.f + sv[k] - mu[k] * mu[k] - es;
-                        nxt[b * PVN_LD + k] = zz;
+                        nxt[lr * PVN_LD + k] = zz;
                         z_out[b * Kz + k] = zz;
                     }
                 kl_out[b] = -0.5f * acc;
             }
         } else if (n0 < N) {
             f32x4 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
             if (op.kind == PVN_BIAS_ACT) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < PVN_NT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[t][r] = P[(16 * t + 4 * q + r) * N + n0 + n];
+                    for (int r = 0; r < 4; ++r) acc[t][r] = P[(rb + 16 * t + 4 * q + r) * N + n0 + n];
                 pvn_prefetch_plain<true>(wnext, nbase, nlane, nstride, nks);
                 PVN_DRAIN_VMEM();
             } else {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
                 const int ks = op.kin >> 2;
                 const float* a0 = cur + n * PVN_LD + q * ks;
-                PVN_SWITCH(ks, (pvn_mma<S_, true>(acc[0], acc[1], a0, a0 + 16 * PVN_LD, wcur, wnext, nbase, nlane, nstride, nks)));
+                PVN_SWITCH(ks, (pvn_mma<S_, true>(acc, a0, wcur, wnext, nbase, nlane, nstride, nks)));
                 PVN_DRAIN_VMEM();
             }
 #ifdef PVN_TRACE
@@ -318,14 +332,14 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
             PVN_T(i * 8 + 2);
 #endif
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < PVN_NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int b = 16 * t + 4 * q + r;
+                    const int lr = 16 * t + 4 * q + r;
                     const float x = acc[t][r] + bcur;
                     const float y = op.act == PV_ACT_ELU ? pv_elu(x) : x;
-                    nxt[b * PVN_LD + n0 + n] = y;
-                    pvn_g(op.out)[b * N + n0 + n] = y;
+                    nxt[lr * PVN_LD + n0 + n] = y;
+                    pvn_g(op.out)[(rb + lr) * N + n0 + n] = y;
                 }
         } else {
             pvn_prefetch_plain<true>(wnext, nbase, nlane, nstride, nks);
@@ -365,9 +379,10 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     int* ops_s = reinterpret_cast<int*>(smem + 2 * 32 * PVN_LD);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, q = lane >> 4;
     const int n0 = wave * 16;
-    if (blockIdx.x != 0) {
+    const int rb = PVN_ROWS * (int)blockIdx.x;  // first batch row of this worker
+    if (blockIdx.x >= PVN_WORKERS) {
         const int p = (int)(blockIdx.x >> 3) - 1;
-        if (update && (blockIdx.x & 7) == 0 && p < nops) {
+        if (update && (int)(blockIdx.x & 7) < PVN_WORKERS && p >= 0 && p < nops) {
             const PvBwdOp op = ops[p];
             if (op.kind == PVN_DENSE) pvn_warm_l2(op.W, op.kin * op.nout, tid);
             if (op.kind != PVN_REPARAM && op.act == PV_ACT_ELU) pvn_warm_l2(op.Y, 32 * op.nout, tid);
@@ -376,9 +391,9 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     }
     if (update) pvn_stage_ops(ops, nops, ops_s, tid);
     const int nrows = st->nrows;
-    const float inv_b = st->inv_b, alpha = st->alpha;
+    const float inv_b = st->inv_b;
 
-    if (tid == 0) {  // loss = mean_b(recon + kl) (popvae.py:423)
+    if (blockIdx.x == 0 && tid == 0) {  // loss = mean_b(recon + kl) (popvae.py:423)
         float sr = xch[32 * W0], sk = 0.f;
         for (int b = 0; b < nrows; ++b) sk += kl[b];
         out3[0] = (sr + sk) * inv_b;
@@ -408,23 +423,23 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     PVN_DRAIN_VMEM();
     {   // dpre of the first op from the exchanged decoder feedback
         if (n0 < W0) {
-            float xv[2][4], yv[2][4];
+            float xv[PVN_NT][4], yv[PVN_NT][4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < PVN_NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int b = 16 * t + 4 * q + r;
+                    const int b = rb + 16 * t + 4 * q + r;
                     xv[t][r] = xch[b * W0 + n0 + n];
                     yv[t][r] = pvn_g(op.Y)[b * W0 + n0 + n];
                 }
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < PVN_NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int b = 16 * t + 4 * q + r;
+                    const int lr = 16 * t + 4 * q + r, b = rb + lr;
                     float d = b < nrows ? xv[t][r] : 0.f;
                     if (op.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[t][r]);
-                    cur[b * PVN_LD + n0 + n] = d;
+                    cur[lr * PVN_LD + n0 + n] = d;
                     pvn_g(op.dpre)[b * W0 + n0 + n] = d;
                 }
         }
@@ -434,35 +449,17 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     for (int i = 0; i < nops; ++i) {
         PVN_T(128 + i * 8 + 0);
         const PvW32 wb = wnext;
-        if (op.kind == PVN_FIRST_BIAS) {
-            // cur = dpre1 (already in global memory for the wide encoder backward); b1 gets its Adam step here
-            const PvBwdOp fo = pvn_get_op<PvBwdOp>(ops_s, i);
-            const int N = fo.nout;
-            if (tid < N) {
-                float g = 0.f;
-#pragma unroll 8
-                for (int b = 0; b < 32; ++b) g += cur[b * PVN_LD + tid];
-                if (MODE == PV_MODE_GRAD) {
-                    pvn_g(fo.mB)[tid] = st->acc ? pvn_g(fo.mB)[tid] + g : g;
-                } else {
-                    float w_ = pvn_g(fo.B)[tid], m_ = pvn_g(fo.mB)[tid], v_ = pvn_g(fo.vB)[tid];
-                    if (MODE == PV_MODE_TRAIN_ACC) g += pvn_g(fo.gB)[tid];
-                    pv_adam(w_, m_, v_, g, alpha, adam);
-                    pvn_g(fo.B)[tid] = w_;
-                    pvn_g(fo.mB)[tid] = m_;
-                    pvn_g(fo.vB)[tid] = v_;
-                }
-            }
-            break;
-        }
+        // dpre1 is in global memory by now (the previous op's epilogue), for the wide encoder backward and for
+        // pvk_narrow_adam, which also sums it over the batch for b1 (the rows are spread over the workers here)
+        if (op.kind == PVN_FIRST_BIAS) break;
         const PvBwdOp nx = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, i + 1);  // the table always ends with FIRST_BIAS
         aim(nx);
         if (op.kind == PVN_REPARAM) {
             pvn_prefetch_plain<false>(wnext, nbase, nlane, 0, nks);
             PVN_DRAIN_VMEM();
             // cur = dz [32][Kz]; result: dpre of the heads op [32][Kh] (cols [0,K) dmu, [K,2K) ds, rest 0)
-            if (tid < 32) {
-                const int b = tid;
+            if (tid < PVN_ROWS) {
+                const int lr = tid, b = rb + tid;  // row in LDS, row of the batch
                 const bool valid = b < nrows;
                 float dmu[16], dsv[16];
 #pragma unroll
@@ -471,20 +468,20 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                     dsv[k] = 0.f;
                     if (k < K && valid) {
                         const float mu = heads[b * Kh + k], s = heads[b * Kh + K + k];
-                        const float es = expf(s), d = cur[b * PVN_LD + k];
+                        const float es = expf(s), d = cur[lr * PVN_LD + k];
                         dmu[k] = d + mu * inv_b;
                         dsv[k] = d * eps[b * K + k] * es + 0.5f * (es - 1.f) * inv_b;
                     }
                 }
                 for (int k = 0; k < Kh; ++k) {
-                    nxt[b * PVN_LD + k] = 0.f;
+                    nxt[lr * PVN_LD + k] = 0.f;
                     pvn_g(nx.dpre)[b * Kh + k] = 0.f;
                 }
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
                     if (k < K) {
-                        nxt[b * PVN_LD + k] = dmu[k];
-                        nxt[b * PVN_LD + K + k] = dsv[k];
+                        nxt[lr * PVN_LD + k] = dmu[k];
+                        nxt[lr * PVN_LD + K + k] = dsv[k];
                         pvn_g(nx.dpre)[b * Kh + k] = dmu[k];
                         pvn_g(nx.dpre)[b * Kh + K + k] = dsv[k];
                     }
@@ -492,12 +489,12 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
         } else if (n0 < op.kin) {
             const int Kin = op.kin, ks = op.nout >> 2;
             const bool to_dpre = nx.kind != PVN_REPARAM;  // REPARAM consumes the raw dz
-            float yv[2][4];
+            float yv[PVN_NT][4];
             if (to_dpre && nx.act == PV_ACT_ELU) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < PVN_NT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) yv[t][r] = pvn_g(nx.Y)[(16 * t + 4 * q + r) * Kin + n0 + n];
+                    for (int r = 0; r < 4; ++r) yv[t][r] = pvn_g(nx.Y)[(rb + 16 * t + 4 * q + r) * Kin + n0 + n];
             }
             f32x4 acc[2];
 #pragma unroll
@@ -506,7 +503,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                 for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
             const float* a0 = cur + n * PVN_LD + q * ks;
             PVN_T(128 + i * 8 + 1);
-            PVN_SWITCH(ks, (pvn_mma<S_, false>(acc[0], acc[1], a0, a0 + 16 * PVN_LD, wb, wnext, nbase, nlane, 0, nks)));
+            PVN_SWITCH(ks, (pvn_mma<S_, false>(acc, a0, wb, wnext, nbase, nlane, 0, nks)));
 #ifdef PVN_TRACE
             asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]));
             PVN_T(128 + i * 8 + 5);
@@ -514,17 +511,17 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
             PVN_DRAIN_VMEM();
             PVN_T(128 + i * 8 + 2);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < PVN_NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int b = 16 * t + 4 * q + r;
+                    const int lr = 16 * t + 4 * q + r, b = rb + lr;
                     float d = acc[t][r];
                     if (to_dpre) {
                         if (nx.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[t][r]);
                         if (b >= nrows) d = 0.f;
                         pvn_g(nx.dpre)[b * Kin + n0 + n] = d;
                     }
-                    nxt[b * PVN_LD + n0 + n] = d;
+                    nxt[lr * PVN_LD + n0 + n] = d;
                 }
         } else {
             pvn_prefetch_plain<false>(wnext, nbase, nlane, 0, nks);
@@ -550,6 +547,26 @@ template <int MODE>
 __global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict__ ops, const PvStep* __restrict__ st,
                                                       PvAdam adam) {
     const PvBwdOp op = ops[blockIdx.y];
+    if (op.kind == PVN_FIRST_BIAS) {
+        // bias of the first (wide) layer: column sums of dpre1 over the batch, 64 columns per block.  kin != 0 marks
+        // the fused narrow stack; the per-layer path (widths above 128) has pvk_bias_bwd do this
+        const int n = blockIdx.x * 64 + threadIdx.x;
+        if (!op.kin || n >= op.nout) return;
+        float g = 0.f;
+#pragma unroll 8
+        for (int b = 0; b < 32; ++b) g += op.dpre[b * op.nout + n];
+        if (MODE == PV_MODE_GRAD) {
+            op.mB[n] = st->acc ? op.mB[n] + g : g;
+        } else {
+            float w_ = op.B[n], m_ = op.mB[n], v_ = op.vB[n];
+            if (MODE == PV_MODE_TRAIN_ACC) g += op.gB[n];
+            pv_adam(w_, m_, v_, g, st->alpha, adam);
+            op.B[n] = w_;
+            op.mB[n] = m_;
+            op.vB[n] = v_;
+        }
+        return;
+    }
     if (op.kind != PVN_DENSE) return;
     const int N = op.nout, Kin = op.kin;
     const int nbn = N >> 5;
