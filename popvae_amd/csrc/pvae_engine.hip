@@ -44,6 +44,7 @@ struct Buf3 {  // weight + Adam slots (+ lazily allocated gradient dump / best s
 struct Dense {  // narrow layer, padded row-major [kin][nout]
     int kin = 0, nout = 0, act = PV_ACT_LINEAR;
     Buf3 W, B;
+    float *wf = nullptr, *wb = nullptr;  // fused narrow stack: operand-order copies of W.w (pvae_narrow.h)
 };
 
 enum TKind { T_W1, T_B1, T_NARROW_W, T_NARROW_B, T_HEAD_W, T_HEAD_B, T_VOUT, T_COUT };
@@ -91,6 +92,7 @@ struct pvae_engine {
     int ts4 = 0;
     // fused narrow stack (width <= 128): op tables in device memory
     bool fused_narrow = false, narrow_warm = true, fuse_fwd = false;
+    bool narrow_pack_dirty = true;  // the operand-order copies lag behind the Keras-layout kernels
     PvFwdOp* d_fwd_ops = nullptr;
     PvBwdOp *d_bwd_ops = nullptr, *d_bwd_ops_grad = nullptr;
     std::vector<float*> dpre_bufs;  // per narrow dense layer, [32][nout]
@@ -357,6 +359,7 @@ int stage_a(pvae_engine* e, int row_offset, bool need_xt, bool fwd_done = false)
 int build_bwd_ops(pvae_engine* e, bool grad, PvBwdOp** out) {
     std::vector<PvBwdOp> ops;
     size_t nd = 0;
+    bool alloc_failed = false;
     auto dense = [&](Dense& d, const float* in, const float* Y) {
         PvBwdOp o{};
         if (nd == e->dpre_bufs.size()) {
@@ -365,6 +368,12 @@ int build_bwd_ops(pvae_engine* e, bool grad, PvBwdOp** out) {
             e->dpre_bufs.push_back(p);
         }
         o.dpre = e->dpre_bufs[nd++];
+        if (e->fused_narrow && !d.wf) {
+            if (hipMalloc(&d.wf, (size_t)d.kin * d.nout * sizeof(float)) != hipSuccess) d.wf = nullptr;
+            if (hipMalloc(&d.wb, (size_t)d.kin * d.nout * sizeof(float)) != hipSuccess) d.wb = nullptr;
+            if (!d.wf || !d.wb) alloc_failed = true;
+        }
+        o.Wf = d.wf; o.Wb = d.wb;
         o.W = d.W.w; o.mW = grad ? d.W.g : d.W.m; o.vW = grad ? nullptr : d.W.v;
         o.B = d.B.w; o.mB = grad ? d.B.g : d.B.m; o.vB = grad ? nullptr : d.B.v;
         o.gW = d.W.g; o.gB = d.B.g;
@@ -387,6 +396,7 @@ int build_bwd_ops(pvae_engine* e, bool grad, PvBwdOp** out) {
     e->n_bwd_ops = (int)ops.size();
     for (auto p : e->dpre_bufs)
         if (!p) return set_err(e, -10, "hipMalloc failed for a dpre buffer");
+    if (alloc_failed) return set_err(e, -10, "hipMalloc failed for an operand-order kernel copy");
     if (!*out) HIPCHK(hipMalloc(out, ops.size() * sizeof(PvBwdOp)));
     HIPCHK(hipMemcpy(*out, ops.data(), ops.size() * sizeof(PvBwdOp), hipMemcpyHostToDevice));
     return 0;
@@ -395,7 +405,7 @@ int build_bwd_ops(pvae_engine* e, bool grad, PvBwdOp** out) {
 int build_fwd_ops(pvae_engine* e) {
     std::vector<PvFwdOp> ops;
     auto dense = [&](const Dense& d, float* out) {
-        ops.push_back(PvFwdOp{d.W.w, d.B.w, out, d.kin, d.nout, d.act, PVN_DENSE});
+        ops.push_back(PvFwdOp{d.wf, d.B.w, out, d.kin, d.nout, d.act, PVN_DENSE});
     };
     const int D = e->D;
     ops.push_back(PvFwdOp{nullptr, e->b1.w, e->h[0], 0, e->Wp, PV_ACT_ELU, PVN_BIAS_ACT});
@@ -411,7 +421,17 @@ int build_fwd_ops(pvae_engine* e) {
     return 0;
 }
 
+// operand-order copies of the narrow kernels: rebuilt when something other than pvk_narrow_adam wrote the kernels
+int ensure_narrow_packed(pvae_engine* e) {
+    if (!e->fused_narrow || !e->narrow_pack_dirty) return 0;
+    hipLaunchKernelGGL(pvk_narrow_pack, dim3(16, e->n_bwd_ops), dim3(256), 0, e->stream, (const PvBwdOp*)e->d_bwd_ops);
+    e->narrow_pack_dirty = false;
+    return launch_check(e, "narrow_pack");
+}
+
 int narrow_fused_fwd(pvae_engine* e, bool encoder_only, bool decoder_only = false) {
+    int rc0;
+    if ((rc0 = ensure_narrow_packed(e))) return rc0;
     const int nops = encoder_only ? e->n_enc_ops : e->n_fwd_ops;
     hipLaunchKernelGGL(pvk_narrow_fwd, dim3(e->narrow_warm ? 8 * (nops + 1) : PVN_WORKERS), dim3(PVN_THREADS), pvn_lds_fwd(), e->stream,
                        e->d_fwd_ops, decoder_only ? e->n_enc_ops : 0, nops, e->P, e->eps, e->K, e->Kz, e->z, e->kl);
@@ -558,6 +578,7 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
     if ((mode == 2 || mode == 4) && !e->d_bwd_ops_grad && (rc = ensure_grad_bufs(e))) return rc;
     const PvBwdOp* table = km == PV_MODE_GRAD ? e->d_bwd_ops_grad : e->d_bwd_ops;
     if (e->fused_narrow) {
+        if ((rc = ensure_narrow_packed(e))) return rc;
         {
         Timer t(e, C_NARROW_BWD);
         const dim3 chain_grid(mode == 1 ? 1 : e->narrow_warm ? 8 * (e->n_bwd_ops + 1) : PVN_WORKERS);
@@ -748,7 +769,7 @@ int full_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, 
 float* pick(Buf3& b, int which) { return which == 0 ? b.w : which == 1 ? b.m : which == 2 ? b.v : b.g; }
 
 int tensor_io(pvae_engine* e, int index, int which, float* host, int64_t count, bool to_device) {
-    if (to_device) e->promised_rows.clear();
+    if (to_device) { e->promised_rows.clear(); e->narrow_pack_dirty = true; }
     if (index < 0 || index >= (int)e->tensors.size()) return set_err(e, -2, "tensor index %d out of range", index);
     const TensorRef& t = e->tensors[index];
     const int64_t expect = t.cols ? t.rows * t.cols : t.rows;
@@ -984,8 +1005,8 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     CK(ensure_loss(e, 1024));
     e->fused_narrow = e->Wp <= 128 && 2 * e->D + 2 <= PVN_MAXOPS && !getenv("PVAE_NO_FUSED_NARROW");
     e->narrow_warm = !getenv("PVAE_NO_NARROW_WARM");
+    CK(build_bwd_ops(e, false, &e->d_bwd_ops));  // also allocates the operand-order copies the forward table points to
     if (e->fused_narrow) CK(build_fwd_ops(e));
-    CK(build_bwd_ops(e, false, &e->d_bwd_ops));
     HK(hipStreamSynchronize(e->stream));
 #undef CK
 #undef HK
@@ -998,6 +1019,9 @@ int pvae_destroy(pvae_engine* e) {
     hipSetDevice(e->dev);
     if (e->own_stream) hipStreamSynchronize(e->own_stream);
     for_each_buf(e, [](Buf3& b) { free3(b); });
+    for (auto& d : e->enc) { hipFree(d.wf); hipFree(d.wb); }
+    for (auto& d : e->dec) { hipFree(d.wf); hipFree(d.wb); }
+    hipFree(e->heads.wf); hipFree(e->heads.wb);
     for (auto p : e->h) hipFree(p);
     for (auto p : e->g) hipFree(p);
     float* fl[] = {e->P, e->headout, e->dheads, e->z, e->dz, e->kl, e->eps, e->xch1, e->dA, e->dB, e->dpre1,
@@ -1079,6 +1103,7 @@ int pvae_reset_optimizer(pvae_engine* e) {
 }
 
 int pvae_init_weights(pvae_engine* e, uint64_t seed) {
+    e->narrow_pack_dirty = true;
     e->promised_rows.clear();
     int rc;
     std::vector<float> buf;
@@ -1336,6 +1361,7 @@ int pvae_snapshot_best(pvae_engine* e) {
 }
 
 int pvae_restore_best(pvae_engine* e) {
+    e->narrow_pack_dirty = true;
     e->promised_rows.clear();
     if (!e->has_best) return set_err(e, -6, "no snapshot taken");
     int rc = 0;

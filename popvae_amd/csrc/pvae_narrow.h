@@ -24,7 +24,7 @@
 enum { PVN_DENSE = 0, PVN_BIAS_ACT = 1, PVN_REPARAM = 2, PVN_FIRST_BIAS = 3 };
 
 struct PvFwdOp {
-    const float* W;  // [kin][nout] row-major (padded to multiples of 32)
+    const float* W;  // operand-order copy of the kernel (pvn_wf_index below); the Keras-layout original is PvBwdOp::W
     const float* b;  // [nout]
     float* out;      // global copy of the layer output [32][nout] (needed by the backward pass)
     int kin, nout, act, kind;
@@ -32,7 +32,7 @@ struct PvFwdOp {
 
 struct PvBwdOp {
     // -- read by the chain kernel for every op (the first PVN_BWD_LEAN dwords) --
-    float* W;            // [kin][nout]
+    float* Wb;           // operand-order copy of the kernel for dIn = dpre * W^T (pvn_wb_index below)
     const float* Y;      // layer output [32][nout]
     float* dpre;         // dLoss/d(pre-activation) [32][nout]: written by the chain kernel, read by pvk_narrow_adam
     int kin, nout, act, kind;
@@ -41,8 +41,27 @@ struct PvBwdOp {
     float *B, *mB, *vB;
     const float* in;     // layer input  [32][kin]
     const float *gW, *gB;  // MODE_TRAIN_ACC: gradients accumulated over the earlier tiles of the batch
+    float* W;            // [kin][nout] row-major (padded to multiples of 32): the Keras-layout kernel
+    float* Wf;           // operand-order copy for the forward chain
 };
 #define PVN_BWD_LEAN 10
+
+// Operand-order copies of a narrow kernel W[kin][nout].  The chain kernels feed v_mfma_f32_16x16x4_f32 straight from
+// global memory: wave w owns 16 output columns, lane (n = lane & 15, q = lane >> 4) the contraction quarter q, and a
+// "chunk" c is the 4 consecutive contraction steps 4c .. 4c + 3.  Read from the Keras layout, one wave instruction
+// touches 4 (forward) or 64 (backward) different cache lines, and the CU's address unit -- not the matrix pipe --
+// bounds a layer.  In these copies a wave's chunk is 1 KB contiguous (lane-major, 16 B per lane):
+//   forward   Wf[((w * kin/16 + c) * 64 + lane) * 4 + e]  = W[q * kin/4 + 4c + e][16w + n]
+//   backward  Wb[((w * nout/16 + c) * 64 + lane) * 4 + e] = W[16w + n][q * nout/4 + 4c + e]
+// pvk_narrow_adam keeps them in step with W; pvk_narrow_pack rebuilds them after any other write to W.
+__host__ __device__ inline int pvn_wf_index(int k, int col, int kin) {
+    const int ks = kin >> 2, q = k / ks, rem = k - q * ks;
+    return ((((col >> 4) * (ks >> 2) + (rem >> 2)) * 64) + q * 16 + (col & 15)) * 4 + (rem & 3);
+}
+__host__ __device__ inline int pvn_wb_index(int k, int col, int nout) {
+    const int ks = nout >> 2, q = col / ks, rem = col - q * ks;
+    return ((((k >> 4) * (ks >> 2) + (rem >> 2)) * 64) + q * 16 + (k & 15)) * 4 + (rem & 3);
+}
 
 // Pointers that come out of an op descriptor have lost their address space: the compiler would use FLAT loads and
 // stores for them, which count on the LDS counter as well -- every wait for an LDS read would then also wait for the
@@ -137,15 +156,20 @@ struct PvW32 {
 // The layer's MFMAs with the NEXT op's 32 B operands loaded in between (8 chunks of 4 spread over the KS/4
 // iterations): issued in one burst ahead of the MFMAs, 8 waves x 32 loads queue up in the CU's one address unit for
 // ~1 us before the first MFMA can issue.  The chunk index is clamped to the next op's own operand count (re-loading
-// its last chunk) so that no load sits under a condition; a wave with nothing to prefetch passes nks = 1, stride 0
-// and any valid address.  FWD: element s at nbase[nlane + s * nstride]; else the contiguous run nbase[nlane + s].
-// nbase / nstride / nks are wave-uniform (SGPRs), so the per-load address arithmetic is scalar; nlane is the lane's part.
-template <int KS, bool FWD>
+// its last chunk) so that no load sits under a condition.  nbase / nch are wave-uniform (SGPRs): scalar address math.
+// chunk c of this wave's next B operands: 1 KB per wave instruction (c is clamped to the op's own chunk count, so that no
+// load sits under a condition; a wave with nothing to prefetch passes nch = 1 and any valid 1 KB)
+__device__ __forceinline__ void pvn_load_chunk(PvW32& wn, int c, const float* nbase, int nch, int lane) {
+    const f32x4 v = pvn_g4(nbase + 256 * min(c, nch - 1))[lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) PVN_WSET(wn, 4 * c + e, v[e]);
+}
+template <int KS>
 __device__ __forceinline__ void pvn_mma(f32x4 (&acc)[2], const float* a0, const PvW32& w, PvW32& wn, const float* nbase,
-                                        int nlane, int nstride, int nks) {
+                                        int nch, int lane) {
     // acc[0], acc[1]: the two row tiles (PVN_NT == 2), or the even-k / odd-k partial sums of the one tile (PVN_NT == 1:
     // two chains keep dependent MFMAs 2 apart; the caller adds them)
-    constexpr int NI = KS / 4;
+    constexpr int NI = KS / 4, LI = NI - NI / 4;  // the last quarter stays free of loads: the drain follows right behind
     f32x4 x0[NI], x1[PVN_NT == 2 ? NI : 1];
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
@@ -155,19 +179,9 @@ __device__ __forceinline__ void pvn_mma(f32x4 (&acc)[2], const float* a0, const 
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
+        if (q < LI) {
 #pragma unroll
-        for (int c = q * 8 / NI; c < (q + 1) * 8 / NI; ++c) {
-            if (FWD) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int sc = min(4 * c + e, nks - 1);
-                    PVN_WSET(wn, 4 * c + e, pvn_g(nbase + sc * nstride)[nlane]);
-                }
-            } else {
-                const f32x4 v = pvn_g4(nbase + 4 * min(c, (nks >> 2) - 1))[nlane >> 2];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) PVN_WSET(wn, 4 * c + e, v[e]);
-            }
+            for (int c = q * 8 / LI; c < (q + 1) * 8 / LI; ++c) pvn_load_chunk(wn, c, nbase, nch, lane);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -183,19 +197,9 @@ __device__ __forceinline__ void pvn_mma(f32x4 (&acc)[2], const float* a0, const 
     if (PVN_NT == 1) acc[0] += acc[1];
 }
 // the same 8 chunks without a layer to hide behind (first op, ops without MFMAs)
-template <bool FWD>
-__device__ __forceinline__ void pvn_prefetch_plain(PvW32& wn, const float* nbase, int nlane, int nstride, int nks) {
+__device__ __forceinline__ void pvn_prefetch_plain(PvW32& wn, const float* nbase, int nch, int lane) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        if (FWD) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) PVN_WSET(wn, 4 * c + e, pvn_g(nbase + min(4 * c + e, nks - 1) * nstride)[nlane]);
-        } else {
-            const f32x4 v = pvn_g4(nbase + 4 * min(c, (nks >> 2) - 1))[nlane >> 2];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) PVN_WSET(wn, 4 * c + e, v[e]);
-        }
-    }
+    for (int c = 0; c < 8; ++c) pvn_load_chunk(wn, c, nbase, nch, lane);
 }
 // Wait-count discipline.  gfx9 has ONE counter for vector loads and stores, and with both kinds outstanding the compiler
 // has to wait for everything at the first use of a loaded register; __syncthreads() adds a full drain per layer on top
@@ -251,15 +255,12 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
     // where this lane's B operands of op `o` start (element s at src[s * stride], s < ks); a wave that has
     // nothing to load for `o` gets a harmless address
     const float* nbase = P;
-    int nlane = 0;
-    int nstride = 0, nks = 1;
+    int nch = 1;
     auto aim = [&](const PvFwdOp& o) {
-        nbase = P; nlane = 0; nstride = 0; nks = 1;
+        nbase = P; nch = 1;
         if (o.kind != PVN_DENSE || n0 >= o.nout) return;
-        nks = o.kin >> 2;
-        nstride = o.nout;
-        nbase = o.W;
-        nlane = (q * nks) * o.nout + n0 + n;
+        nch = o.kin >> 4;
+        nbase = o.W + wave * nch * 256;
     };
     if (op0 > 0) {  // decoder.predict: start behind REPARAM with z (already in z_out) as the activation
         if (tid < PVN_ROWS)
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
     }
     PvFwdOp op = pvn_get_op<PvFwdOp>(ops_s, op0);
     aim(op);
-    pvn_prefetch_plain<true>(wnext, nbase, nlane, nstride, nks);
+    pvn_prefetch_plain(wnext, nbase, nch, lane);
     PVN_DRAIN_VMEM();
     for (int i = op0; i < nops; ++i) {
         PVN_T(i * 8 + 0);
@@ -277,11 +278,11 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
         const float bcur = pvn_g(op.b)[n0 < op.nout ? n0 + n : 0];
         const PvFwdOp nx = i + 1 < nops ? pvn_get_op<PvFwdOp>(ops_s, i + 1) : op;
         if (i + 1 < nops) aim(nx);
-        else { nbase = P; nlane = 0; nstride = 0; nks = 1; }
+        else { nbase = P; nch = 1; }
         const int N = op.nout;
         PVN_T(i * 8 + 1);
         if (op.kind == PVN_REPARAM) {
-            pvn_prefetch_plain<true>(wnext, nbase, nlane, nstride, nks);
+            pvn_prefetch_plain(wnext, nbase, nch, lane);
             PVN_DRAIN_VMEM();
             // cur holds the heads output: cols [0,K) = z_mean, [K,2K) = z_log_var; nxt gets z (padded to Kz)
             if (tid < PVN_ROWS) {
@@ -319,12 +320,12 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
                 for (int t = 0; t < PVN_NT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[t][r] = P[(rb + 16 * t + 4 * q + r) * N + n0 + n];
-                pvn_prefetch_plain<true>(wnext, nbase, nlane, nstride, nks);
+                pvn_prefetch_plain(wnext, nbase, nch, lane);
                 PVN_DRAIN_VMEM();
             } else {
                 const int ks = op.kin >> 2;
                 const float* a0 = cur + n * PVN_LD + q * ks;
-                PVN_SWITCH(ks, (pvn_mma<S_, true>(acc, a0, wcur, wnext, nbase, nlane, nstride, nks)));
+                PVN_SWITCH(ks, (pvn_mma<S_>(acc, a0, wcur, wnext, nbase, nch, lane)));
                 PVN_DRAIN_VMEM();
             }
 #ifdef PVN_TRACE
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
                     pvn_g(op.out)[(rb + lr) * N + n0 + n] = y;
                 }
         } else {
-            pvn_prefetch_plain<true>(wnext, nbase, nlane, nstride, nks);
+            pvn_prefetch_plain(wnext, nbase, nch, lane);
             PVN_DRAIN_VMEM();
         }
         PVN_T(i * 8 + 3);
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
         const int p = (int)(blockIdx.x >> 3) - 1;
         if (update && (int)(blockIdx.x & 7) < PVN_WORKERS && p >= 0 && p < nops) {
             const PvBwdOp op = ops[p];
-            if (op.kind == PVN_DENSE) pvn_warm_l2(op.W, op.kin * op.nout, tid);
+            if (op.kind == PVN_DENSE) pvn_warm_l2(op.Wb, op.kin * op.nout, tid);
             if (op.kind != PVN_REPARAM && op.act == PV_ACT_ELU) pvn_warm_l2(op.Y, 32 * op.nout, tid);
         }
         return;
@@ -406,20 +407,18 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     PvW32 wnext;
 #pragma unroll
     for (int s = 0; s < 16; ++s) wnext.lo[s] = wnext.hi[s] = 0.f;
-    // B operands of op o: lane (k = n, q) of wave w reads the run W[16w + k][q * ks + s], s < ks = nout / 4
+    // B operands of op o: lane (k = n, q) of wave w needs the run W[16w + k][q * ks + s], s < ks = nout / 4
     const float* nbase = xch;
-    int nlane = 0;
-    int nks = 4;
+    int nch = 1;
     auto aim = [&](const PvBwdOp& o) {
-        nbase = xch; nlane = 0; nks = 4;
+        nbase = xch; nch = 1;
         if (o.kind != PVN_DENSE || n0 >= o.kin) return;
-        nks = o.nout >> 2;
-        nbase = o.W;
-        nlane = (n0 + n) * o.nout + q * nks;
+        nch = o.nout >> 4;
+        nbase = o.Wb + wave * nch * 256;
     };
     PvBwdOp op = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, 0);
     aim(op);
-    pvn_prefetch_plain<false>(wnext, nbase, nlane, 0, nks);
+    pvn_prefetch_plain(wnext, nbase, nch, lane);
     PVN_DRAIN_VMEM();
     {   // dpre of the first op from the exchanged decoder feedback
         if (n0 < W0) {
@@ -455,7 +454,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
         const PvBwdOp nx = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, i + 1);  // the table always ends with FIRST_BIAS
         aim(nx);
         if (op.kind == PVN_REPARAM) {
-            pvn_prefetch_plain<false>(wnext, nbase, nlane, 0, nks);
+            pvn_prefetch_plain(wnext, nbase, nch, lane);
             PVN_DRAIN_VMEM();
             // cur = dz [32][Kz]; result: dpre of the heads op [32][Kh] (cols [0,K) dmu, [K,2K) ds, rest 0)
             if (tid < PVN_ROWS) {
@@ -503,7 +502,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                 for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
             const float* a0 = cur + n * PVN_LD + q * ks;
             PVN_T(128 + i * 8 + 1);
-            PVN_SWITCH(ks, (pvn_mma<S_, false>(acc, a0, wb, wnext, nbase, nlane, 0, nks)));
+            PVN_SWITCH(ks, (pvn_mma<S_>(acc, a0, wb, wnext, nbase, nch, lane)));
 #ifdef PVN_TRACE
             asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]));
             PVN_T(128 + i * 8 + 5);
@@ -524,7 +523,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                     nxt[lr * PVN_LD + n0 + n] = d;
                 }
         } else {
-            pvn_prefetch_plain<false>(wnext, nbase, nlane, 0, nks);
+            pvn_prefetch_plain(wnext, nbase, nch, lane);
             PVN_DRAIN_VMEM();
         }
         PVN_T(128 + i * 8 + 3);
@@ -607,6 +606,11 @@ __global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict_
             (op.W + ro)[voff] = w_;
             (op.mW + ro)[voff] = m_;
             (op.vW + ro)[voff] = v_;
+            if (op.Wf) {  // the chain kernels' operand-order copies
+                const int k = kb * 32 + 4 * h + (r & 3) + 8 * (r >> 2), col = nb * 32 + c;
+                op.Wf[pvn_wf_index(k, col, Kin)] = w_;
+                op.Wb[pvn_wb_index(k, col, N)] = w_;
+            }
         }
     }
     if (kb == 0 && h == 0) {  // bias of these 32 columns: column sums of dpre
@@ -623,6 +627,25 @@ __global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict_
             op.B[n] = w_;
             op.mB[n] = m_;
             op.vB[n] = v_;
+        }
+    }
+}
+
+// Rebuilds the operand-order copies from the Keras-layout kernels (after set_weights / init / restore).  grid = (16, n_ops),
+// 256 threads; destination-ordered, so the writes are coalesced.
+__global__ __launch_bounds__(256) void pvk_narrow_pack(const PvBwdOp* __restrict__ ops) {
+    const PvBwdOp op = ops[blockIdx.y];
+    if (op.kind != PVN_DENSE || !op.Wf) return;
+    const int N = op.nout, Kin = op.kin, total = N * Kin;
+    for (int d = blockIdx.x * 256 + threadIdx.x; d < total; d += gridDim.x * 256) {
+        const int e = d & 3, lane = (d >> 2) & 63, rest = d >> 8, n = lane & 15, q = lane >> 4;
+        {   // forward copy: rest = w * (Kin / 16) + c
+            const int nch = Kin >> 4, w = rest / nch, c = rest - w * nch;
+            op.Wf[d] = op.W[(q * (Kin >> 2) + 4 * c + e) * N + 16 * w + n];
+        }
+        {   // backward copy: rest = w * (N / 16) + c
+            const int nch = N >> 4, w = rest / nch, c = rest - w * nch;
+            op.Wb[d] = op.W[(16 * w + n) * N + q * (N >> 2) + 4 * c + e];
         }
     }
 }
