@@ -138,6 +138,9 @@ int pvae_stage_encode(pvae_engine* e, int32_t n, float* z_mean, float* z_log_var
  * engine stream; names: "enc_fwd", "dec", "enc_bwd", "narrow_fwd", "narrow_bwd", "gather" */
 int pvae_set_timing(pvae_engine* e, int enabled);
 int pvae_get_timing(pvae_engine* e, const char* name, float* ms_total, int64_t* launches);
+/* as pvae_set_timing(e, 1), but only the named category gets events: every event pair costs the stream ~5-10 us per
+ * launch, which is why a run that measures throughput times its dominant kernel only */
+int pvae_set_timing_only(pvae_engine* e, const char* name);
 
 #ifdef __cplusplus
 }

@@ -116,6 +116,7 @@ struct pvae_engine {
     PvAdam adam{};
     // timing
     bool timing = false;
+    unsigned timing_mask = ~0u;  // categories that get events (an event pair costs ~5-10 us of stream time per launch)
     struct Ev { hipEvent_t a, b; int cat; };
     std::vector<Ev> evs;
     size_t ev_used = 0;
@@ -216,7 +217,7 @@ struct Timer {
     pvae_engine* e;
     bool on;
     size_t idx = 0;
-    Timer(pvae_engine* e_, int cat) : e(e_), on(e_->timing) {
+    Timer(pvae_engine* e_, int cat) : e(e_), on(e_->timing && ((e_->timing_mask >> cat) & 1u)) {
         if (!on) return;
         if (e->ev_used == e->evs.size()) {
             pvae_engine::Ev ev;
@@ -340,7 +341,7 @@ int stage_a(pvae_engine* e, int row_offset, bool need_xt, bool fwd_done = false)
     }
     if (fwd_done) {
         // the previous step's pvk_enc_bwd<.., FUSE = 1> already left this batch's partial sums in encpart
-        hipLaunchKernelGGL(pvk_reduce_parts, dim3(32 * e->Wp / 64), dim3(256), 0, e->stream, e->encpart, e->encb_wgs / e->ngrp,
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(32 * e->Wp)), dim3(256), 0, e->stream, e->encpart, e->encb_wgs / e->ngrp,
                            32 * e->Wp, 0.5f, e->P, (const float*)nullptr, (float*)nullptr);
         if ((rc = launch_check(e, "enc_reduce"))) return rc;
     } else {
@@ -348,7 +349,7 @@ int stage_a(pvae_engine* e, int row_offset, bool need_xt, bool fwd_done = false)
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_enc_fwd<N_>, dim3(e->enc_wgs), dim3(256), lds_enc_fwd(N_), e->stream, e->W1.w, e->geno,
                                               e->row_bytes, e->d_rows, e->st, row_offset, e->nblk, e->ngrp, e->encpart, e->ts4));
         if ((rc = launch_check(e, "enc_fwd"))) return rc;
-        hipLaunchKernelGGL(pvk_reduce_parts, dim3(32 * e->Wp / 64), dim3(256), 0, e->stream, e->encpart, e->enc_wgs / e->ngrp, 32 * e->Wp,
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(32 * e->Wp)), dim3(256), 0, e->stream, e->encpart, e->enc_wgs / e->ngrp, 32 * e->Wp,
                            0.5f, e->P, (const float*)nullptr, (float*)nullptr);
         if ((rc = launch_check(e, "enc_reduce"))) return rc;
     }
@@ -516,7 +517,7 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
         if ((rc = launch_check(e, "dec"))) return rc;
         const int n_dg = mode == 1 ? 0 : 32 * e->Wp;
         // eval: only the recon sums are produced (they live behind the dg block of the exchange buffer)
-        hipLaunchKernelGGL(pvk_reduce_parts, dim3(n_dg ? n_dg / 64 : 1), dim3(256), 0, e->stream, e->dgpart, e->dec_wgs, n_dg, 1.0f,
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(n_dg)), dim3(256), 0, e->stream, e->dgpart, e->dec_wgs, n_dg, 1.0f,
                            e->xch1, e->losspart, e->xch1 + 32 * e->Wp);
         if ((rc = launch_check(e, "dec_reduce"))) return rc;
     }
@@ -692,8 +693,13 @@ int begin_batch(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
     memcpy(sl.host, rows, n * sizeof(int));
     if (eps) memcpy(sl.host + 32 * sizeof(int), eps, (size_t)n * e->K * sizeof(float));
     HIPCHK(hipMemcpyAsync(e->d_rows, sl.host, n * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(pvk_step_begin, dim3(1), dim3(64), 0, e->stream, e->st, (const int*)nullptr, n, e->cfg.batch_size, 0,
-                       train ? 1 : 0, e->adam.b1, e->adam.b2);
+    if (eps)
+        hipLaunchKernelGGL(pvk_step_begin, dim3(1), dim3(64), 0, e->stream, e->st, (const int*)nullptr, n, e->cfg.batch_size, 0,
+                           train ? 1 : 0, e->adam.b1, e->adam.b2);
+    else
+        hipLaunchKernelGGL(pvk_step_begin_eps, dim3(1), dim3(1024), 0, e->stream, e->st, (const int*)nullptr, n,
+                           e->cfg.batch_size, 0, train ? 1 : 0, e->adam.b1, e->adam.b2, e->eps, 32 * e->K, e->cfg.seed,
+                           e->d_counter);
     if ((rc = launch_check(e, "step_begin"))) return rc;
     if (eps) {
         HIPCHK(hipMemcpyAsync(e->eps, sl.host + 32 * sizeof(int), (size_t)n * e->K * sizeof(float), hipMemcpyHostToDevice,
@@ -703,8 +709,6 @@ int begin_batch(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
     } else {
         HIPCHK(hipEventRecord(sl.ev, e->stream));
         sl.pending = true;
-        hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, 32 * e->K, e->cfg.seed, e->d_counter);
-        if ((rc = launch_check(e, "gen_eps"))) return rc;
     }
     return 0;
 }
@@ -1201,9 +1205,8 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
                 if (s + 1 < st_tr) { next_off = (s + 1) * B; next_n = std::min(B, n_train - next_off); fuse = true; }
                 else if (st_va > 0) { next_off = n_train; next_n = std::min(B, (int)n_val); fuse = true; }
             }
-            hipLaunchKernelGGL(pvk_step_begin, dim3(1), dim3(64), 0, e->stream, e->st, (const int*)e->d_ntotal, 0, B, s, phase == 0 ? 1 : 0,
-                               e->adam.b1, e->adam.b2);
-            hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, 32 * e->K, e->cfg.seed, e->d_counter);
+            hipLaunchKernelGGL(pvk_step_begin_eps, dim3(1), dim3(1024), 0, e->stream, e->st, (const int*)e->d_ntotal, 0, B, s,
+                               phase == 0 ? 1 : 0, e->adam.b1, e->adam.b2, e->eps, 32 * e->K, e->cfg.seed, e->d_counter);
             if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
             if ((rc = stage_a(e, base + s * B, true, fwd_done))) return rc;
             if ((rc = stage_b(e, phase == 0 ? 0 : 1))) return rc;
@@ -1442,8 +1445,20 @@ int pvae_stage_c_next(pvae_engine* e, int mode, float* out3, const int32_t* next
 int pvae_set_timing(pvae_engine* e, int enabled) {
     flush_timing(e);
     e->timing = enabled != 0;
+    e->timing_mask = ~0u;
     for (int i = 0; i < C_NCAT; ++i) { e->cat_ms[i] = 0; e->cat_n[i] = 0; }
     return 0;
+}
+int pvae_set_timing_only(pvae_engine* e, const char* name) {
+    int rc = pvae_set_timing(e, 1);
+    if (rc) return rc;
+    for (int i = 0; i < C_NCAT; ++i)
+        if (!strcmp(name, kCatNames[i])) {
+            e->timing_mask = 1u << i;
+            return 0;
+        }
+    e->timing = false;
+    return set_err(e, -2, "unknown timing category %s", name);
 }
 int pvae_get_timing(pvae_engine* e, const char* name, float* ms_total, int64_t* launches) {
     flush_timing(e);

@@ -200,21 +200,25 @@ __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fixed-order reduction of per-workgroup partials: out[e] = scale * sum_p part[p*n + e], e < n (n % 64 == 0),
-// and optionally sout[0] = sum_p spart[p].  Block = 16 float4 columns x 16 slices; slice s adds partials
-// s, s+16, ... in order, then the 16 slice sums are added in order: bitwise reproducible.
+// Fixed-order reduction of per-workgroup partials: out[e] = scale * sum_p part[p*n + e], e < n (n % 16 == 0),
+// and optionally sout[0] = sum_p spart[p].  grid = n / 16 blocks (PV_REDUCE_GRID); block = 4 float4 columns x 64
+// slices; slice s adds partials s, s+64, ... in order (<= 8 independent loads in flight per thread at 512 partials: the
+// kernel is pure latency, 64 wide blocks of 32 dependent steps each took 10 us), then the 64 slice sums are added in
+// order: bitwise reproducible.
 // ---------------------------------------------------------------------------------------------
+#define PV_REDUCE_GRID(n) ((n) > 0 ? (n) / 16 : 1)
 __global__ __launch_bounds__(256) void pvk_reduce_parts(const float* __restrict__ part, int nparts, int n, float scale,
                                                         float* __restrict__ out, const float* __restrict__ spart,
                                                         float* __restrict__ sout) {
-    __shared__ f32x4 sm[16][16];
+    __shared__ f32x4 sm[64][4];
     __shared__ float ss[256];
-    const int tid = threadIdx.x, col = tid & 15, slice = tid >> 4;
-    if ((int)blockIdx.x * 64 < n) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(part) + blockIdx.x * 16 + col;
+    const int tid = threadIdx.x, col = tid & 3, slice = tid >> 2;
+    if ((int)blockIdx.x * 16 < n) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(part) + blockIdx.x * 4 + col;
         const int n4 = n >> 2;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int p = slice; p < nparts; p += 16) acc += src[(int64_t)p * n4];
+#pragma unroll 8
+        for (int p = slice; p < nparts; p += 64) acc += src[(int64_t)p * n4];
         sm[slice][col] = acc;
     }
     if (blockIdx.x == 0 && spart) {
@@ -223,11 +227,11 @@ __global__ __launch_bounds__(256) void pvk_reduce_parts(const float* __restrict_
         ss[tid] = a;
     }
     __syncthreads();
-    if ((int)blockIdx.x * 64 < n && tid < 16) {
+    if ((int)blockIdx.x * 16 < n && tid < 4) {
         f32x4 acc = sm[0][tid];
-#pragma unroll
-        for (int s2 = 1; s2 < 16; ++s2) acc += sm[s2][tid];
-        reinterpret_cast<f32x4*>(out)[blockIdx.x * 16 + tid] = acc * scale;
+#pragma unroll 8
+        for (int s2 = 1; s2 < 64; ++s2) acc += sm[s2][tid];
+        reinterpret_cast<f32x4*>(out)[blockIdx.x * 4 + tid] = acc * scale;
     }
     if (blockIdx.x == 0 && spart && tid == 0) {
         float a = 0.f;
@@ -1063,6 +1067,41 @@ __global__ void pvk_gen_eps(float* __restrict__ eps, int n, uint64_t seed, uint6
     __syncthreads();
     if (i == 0) *counter = call + 1;
 }
+
+// pvk_step_begin + pvk_gen_eps in one launch of 1024 threads: the two used to be back-to-back 4 us kernels at
+// the head of every step
+__global__ __launch_bounds__(1024) void pvk_step_begin_eps(PvStep* st, const int* __restrict__ n_total_ptr, int n_total_val,
+                                                           int batch, int step, int train, float b1, float b2,
+                                                           float* __restrict__ eps, int n_eps, uint64_t seed,
+                                                           uint64_t* __restrict__ counter) {
+    const int i = threadIdx.x;
+    const uint64_t call = *counter;
+    if (i == 0) {
+        int remaining = (n_total_ptr ? *n_total_ptr : n_total_val) - step * batch;
+        int nrows = remaining < batch ? remaining : batch;
+        if (nrows < 0) nrows = 0;
+        st->nrows = nrows;
+        st->inv_b = nrows > 0 ? 1.f / (float)nrows : 0.f;
+        st->step_in_epoch = step;
+        st->acc = 0;
+        if (train) {
+            int t = st->t + 1;
+            st->t = t;
+            float b1p = powf(b1, (float)t), b2p = powf(b2, (float)t);
+            st->alpha = st->lr * sqrtf(1.f - b2p) / (1.f - b1p);
+        }
+    }
+    if (i < n_eps) {
+        uint32_t o[4];
+        pv_philox((uint32_t)i, 0u, (uint32_t)call, (uint32_t)(call >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        eps[i] = sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    }
+    __syncthreads();
+    if (i == 0) *counter = call + 1;
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // Layout conversion between Keras row-major tensors and the fragment-native tiled layout.

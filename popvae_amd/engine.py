@@ -20,7 +20,7 @@ ENGINE_SYMBOLS = [
     "pvae_get_tensor", "pvae_init_weights", "pvae_get_moment", "pvae_reset_optimizer", "pvae_set_lr", "pvae_get_lr",
     "pvae_train_step", "pvae_eval_step", "pvae_grad_step", "pvae_get_grad", "pvae_train_epoch", "pvae_encode",
     "pvae_decode", "pvae_pca_gram", "pvae_snapshot_best", "pvae_restore_best", "pvae_exchange_buffer", "pvae_exchange_copy", "pvae_stage_a", "pvae_stage_b",
-    "pvae_stage_c", "pvae_stage_c_next", "pvae_stage_encode", "pvae_set_timing", "pvae_get_timing",
+    "pvae_stage_c", "pvae_stage_c_next", "pvae_stage_encode", "pvae_set_timing", "pvae_get_timing", "pvae_set_timing_only",
 ]
 
 
@@ -83,6 +83,7 @@ def lib():
         L.pvae_stage_c_next.argtypes = [vp, C.c_int, _fopt, C.POINTER(C.c_int32), i32]
         L.pvae_stage_encode.argtypes = [vp, i32, _fopt, _fopt, _fopt]
         L.pvae_set_timing.argtypes = [vp, C.c_int]
+        L.pvae_set_timing_only.argtypes = [vp, C.c_char_p]
         L.pvae_get_timing.argtypes = [vp, C.c_char_p, _fopt, C.POINTER(i64)]
         _lib = L
     return _lib
@@ -309,8 +310,13 @@ class Engine:
         return mu, lv, z
 
     # -- measurement -----------------------------------------------------------------------------
-    def set_timing(self, on):
-        self._ck(lib().pvae_set_timing(self._h, int(bool(on))))
+    def set_timing(self, on, only=None):
+        """HIP-event timing of the kernels by category; ``only="dec"`` restricts the events to one category (each
+        event pair costs the stream ~5-10 us per launch)."""
+        if on and only:
+            self._ck(lib().pvae_set_timing_only(self._h, only.encode()))
+        else:
+            self._ck(lib().pvae_set_timing(self._h, int(bool(on))))
 
     def get_timing(self, name):
         ms, n = C.c_float(), C.c_int64()
