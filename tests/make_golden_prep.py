@@ -1,6 +1,8 @@
 """Generates tests/golden/pabu_prep_seed42.json from the oracle (numpy legacy RNG called directly =
 the reference's own RNG library) on the reference's fixture VCF.  Run in the build container only
-(/root/reference is not on the GPU box):  python tests/make_golden_prep.py"""
+(/root/reference is not on the GPU box):  python tests/make_golden_prep.py
+The VCF itself travels as tests/golden/pabu_test_genotypes.vcf.gz (gzip -9 of the reference's data file, a fixture the
+reference's own --test run holds) together with its sample sheet pabu_test_sample_data.txt."""
 import hashlib
 import json
 import os
