@@ -524,38 +524,41 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
     return 0;
 }
 
-int enc_bwd_launch(pvae_engine* e, int km, bool fuse = false, int next_off = 0, int next_n = 0) {
+int enc_bwd_launch(pvae_engine* e, int km, bool fuse = false, int next_off = 0, int next_n = 0, const PvBwdOp* adam_ops = nullptr) {
     int rc;
     Timer t(e, C_ENC_BWD);
     const uint8_t* nog = nullptr;
     const int* nor = nullptr;
     float* nof = nullptr;
     const float* nogw = nullptr;
+    const PvBwdOp* noops = nullptr;
+    const int adam_units = adam_ops ? 16 * e->n_bwd_ops : 0;
+    if (adam_units > 4 * e->encb_wgs) return set_err(e, -6, "narrow Adam units exceed the wide encoder backward's waves");
     if (km == PV_MODE_GRAD) {
         if (!e->W1.g && (rc = allocf(e, &e->W1.g, e->W1.n))) return rc;
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_GRAD, 0>), dim3(e->encb_wgs), dim3(256),
                                               lds_enc_bwd(e->Wp), e->stream, e->W1.w, (float*)nullptr, (float*)nullptr,
                                               (float*)nullptr, e->W1.g, (float*)nullptr, e->dpre1, e->Wp, e->Xt, e->nblk,
-                                              e->ngrp, e->st, e->adam, nog, (int64_t)0, nor, 0, 0, nof, e->ts4, nogw));
+                                              e->ngrp, e->st, e->adam, nog, (int64_t)0, nor, 0, 0, nof, e->ts4, nogw, noops, 0));
     } else if (km == PV_MODE_TRAIN_ACC) {
         if (!e->W1.g) return set_err(e, -6, "train-with-accumulated-gradients step without a gradient dump");
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN_ACC, 0>), dim3(e->encb_wgs), dim3(256),
                                               lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
                                               e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam, nog,
-                                              (int64_t)0, nor, 0, 0, nof, e->ts4, (const float*)e->W1.g));
+                                              (int64_t)0, nor, 0, 0, nof, e->ts4, (const float*)e->W1.g, noops, 0));
         e->W1.swap();
     } else if (fuse) {
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 1>), dim3(e->encb_wgs), dim3(256),
                                               lds_enc_bwd_fused(N_, e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
                                               e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam,
                                               (const uint8_t*)e->geno, e->row_bytes, (const int*)e->d_rows, next_off, next_n,
-                                              e->encpart, e->ts4, nogw));
+                                              e->encpart, e->ts4, nogw, adam_ops, adam_units));
         e->W1.swap();
     } else {
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 0>), dim3(e->encb_wgs), dim3(256),
                                               lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
                                               e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam, nog,
-                                              (int64_t)0, nor, 0, 0, nof, e->ts4, nogw));
+                                              (int64_t)0, nor, 0, 0, nof, e->ts4, nogw, adam_ops, adam_units));
         e->W1.swap();
     }
     return launch_check(e, "enc_bwd");
@@ -580,6 +583,9 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
     const PvBwdOp* table = km == PV_MODE_GRAD ? e->d_bwd_ops_grad : e->d_bwd_ops;
     if (e->fused_narrow) {
         if ((rc = ensure_narrow_packed(e))) return rc;
+        // plain training: the narrow layers' dW + Adam units ride on the first workgroups of the wide encoder backward
+        // (one unit per wave), unless the SNP shard is so small that its grid has fewer waves than there are units
+        const bool ride = mode == 0 && 16 * e->n_bwd_ops <= 4 * e->encb_wgs;
         {
         Timer t(e, C_NARROW_BWD);
         const dim3 chain_grid(mode == 1 ? 1 : e->narrow_warm ? 8 * (e->n_bwd_ops + 1) : PVN_WORKERS);
@@ -594,12 +600,12 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
             hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_GRAD>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam);
         else if (km == PV_MODE_TRAIN_ACC)
             hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN_ACC>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam);
-        else if (mode == 0)
+        if (mode == 0 && !ride)
             hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam);
         if ((rc = launch_check(e, "narrow_bwd"))) return rc;
         }
         if (mode == 1) return 0;
-        return enc_bwd_launch(e, km, fuse, next_off, next_n);
+        return enc_bwd_launch(e, km, fuse, next_off, next_n, ride ? table : nullptr);
     }
     hipLaunchKernelGGL(pvk_loss_final, dim3(1), dim3(64), 0, e->stream, e->xch1 + 32 * e->Wp, e->kl, e->st, d_out3);
     if ((rc = launch_check(e, "loss_final"))) return rc;

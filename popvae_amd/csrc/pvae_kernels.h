@@ -923,6 +923,13 @@ __global__ void pvk_loss_final(const float* __restrict__ recon, const float* __r
 // batch's genotype codes -- the next step's first-layer forward (pvk_enc_fwd) rides along, which saves one
 // full read of W1 (4 of the 52 bytes per wide parameter and step).  Partials go to fpart[workgroup][32][Wp]
 // exactly as pvk_enc_fwd writes them.
+// ADAM_UNITS > 0 (training, fused narrow stack): the first ADAM_UNITS / 4 workgroups first do one unit each per wave of
+// the narrow layers' weight-gradient + Adam work (pvn_adam_unit in pvae_narrow.h; independent of everything this kernel
+// touches), which otherwise is an 8 us launch of 208 single-wave workgroups on an otherwise idle chip.
+struct PvBwdOp;
+template <int MODE>
+__device__ __forceinline__ void pvn_adam_unit(const PvBwdOp* __restrict__ ops, int bx, int by, int lane_,
+                                              const PvStep* __restrict__ st, PvAdam adam);
 template <int NWB, int MODE, int FUSE>
 __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ W1, const float* __restrict__ mW,
                                                    const float* __restrict__ vW, float* __restrict__ W1o,
@@ -931,10 +938,15 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
                                                    int nblk, int ngrp, const PvStep* st, PvAdam adam,
                                                    const uint8_t* __restrict__ geno, int64_t row_bytes,
                                                    const int* __restrict__ rows, int next_off, int next_n,
-                                                   float* __restrict__ fpart, int ts, const float* __restrict__ gW) {
+                                                   float* __restrict__ fpart, int ts, const float* __restrict__ gW,
+                                                   const PvBwdOp* __restrict__ adam_ops, int adam_units) {
     constexpr int WG_UNITS = NWB * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [ngrp][32][WG_UNITS]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    if (MODE == PV_MODE_TRAIN && adam_ops) {
+        const int unit = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+        if (unit < adam_units) pvn_adam_unit<PV_MODE_TRAIN>(adam_ops, unit & 15, unit >> 4, lane, st, adam);
+    }
     // a workgroup stays on ONE unit group (grp = blockIdx.x % ngrp; gridDim.x is a multiple of ngrp): its waves'
     // forward fragments (FUSE) can then be summed, and neighbouring workgroups still sweep one window of HBM
     const int grp = blockIdx.x % ngrp;

@@ -542,14 +542,16 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
 // All operands come straight from global memory in 128-byte rows; the accumulator layout (lane = column n,
 // registers = rows k) is also the layout of the W / m / v loads and stores.
 // ---------------------------------------------------------------------------------------------
+// One unit of that work = one wave: (bx, by) = (32x32 block index within the layer, op index); as a device function so
+// that the wide encoder backward can carry the units on its first workgroups (pvk_enc_bwd) instead of a launch of its own.
 template <int MODE>
-__global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict__ ops, const PvStep* __restrict__ st,
-                                                      PvAdam adam) {
-    const PvBwdOp op = ops[blockIdx.y];
+__device__ __forceinline__ void pvn_adam_unit(const PvBwdOp* __restrict__ ops, int bx, int by, int lane_,
+                                              const PvStep* __restrict__ st, PvAdam adam) {
+    const PvBwdOp op = ops[by];
     if (op.kind == PVN_FIRST_BIAS) {
         // bias of the first (wide) layer: column sums of dpre1 over the batch, 64 columns per block.  kin != 0 marks
         // the fused narrow stack; the per-layer path (widths above 128) has pvk_bias_bwd do this
-        const int n = blockIdx.x * 64 + threadIdx.x;
+        const int n = bx * 64 + lane_;
         if (!op.kin || n >= op.nout) return;
         float g = 0.f;
 #pragma unroll 8
@@ -569,9 +571,9 @@ __global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict_
     if (op.kind != PVN_DENSE) return;
     const int N = op.nout, Kin = op.kin;
     const int nbn = N >> 5;
-    const int kb = blockIdx.x / nbn, nb = blockIdx.x - kb * nbn;
+    const int kb = bx / nbn, nb = bx - kb * nbn;
     if (kb * 32 >= Kin) return;
-    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    const int lane = lane_, c = lane & 31, h = lane >> 5;
     const float alpha = st->alpha;
     const int voff = (kb * 32 + 4 * h) * N + nb * 32 + c;
     float wv[16], mv[16], vv[16];
@@ -629,6 +631,12 @@ __global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict_
             op.vB[n] = v_;
         }
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict__ ops, const PvStep* __restrict__ st,
+                                                      PvAdam adam) {
+    pvn_adam_unit<MODE>(ops, blockIdx.x, blockIdx.y, threadIdx.x, st, adam);
 }
 
 // Rebuilds the operand-order copies from the Keras-layout kernels (after set_weights / init / restore).  grid = (16, n_ops),
