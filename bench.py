@@ -151,8 +151,10 @@ def main():
 
     losses = []
 
+    native = sharded and step_engine.native  # engine-owned RCCL communicator: the C-side loop works under sharding too
+
     def run(rows2d):
-        if not sharded:
+        if not sharded or native:
             # C-side loop: exactly len(rows2d) train steps, no validation rows
             losses.append(eng.train_epoch(rows2d.reshape(-1), np.zeros(0, np.int32))[0])
         else:
@@ -201,7 +203,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     for r in vr:
-        if not sharded:
+        if not sharded or native:
             eng.eval_step(r, None, want_loss=False)
         else:
             step_engine._step(r, None, E.MODE_EVAL, want_loss=False)
@@ -249,7 +251,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} samples x {L} SNPs, depth {D}, width {W}, latent {K}, "
                                    f"batch {B}, fp32 weights + fused Keras-Adam (lr {args.lr:g})",
-                       "parallelism": f"snp-shard x{world}" if world > 1 else "single GPU"},
+                       "parallelism": (f"snp-shard x{world}, " + ("all-reduces enqueued by the engine (own RCCL communicator)"
+                                                                   if native else "host-driven all-reduces (torch.distributed)"))
+                       if sharded else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "pvk_dec (fused wide decoder: logits+sigmoid+BCE+dlogits+dV+Adam)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,

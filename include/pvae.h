@@ -134,6 +134,19 @@ int pvae_stage_c(pvae_engine* e, int mode, float* out3);
 int pvae_stage_c_next(pvae_engine* e, int mode, float* out3, const int32_t* next_rows, int32_t next_n);
 int pvae_stage_encode(pvae_engine* e, int32_t n, float* z_mean, float* z_log_var, float* z);
 
+/* SNP-axis sharding without host code in the step: the engine's own RCCL communicator.  One rank calls
+ * pvae_comm_unique_id (ncclGetUniqueId, 128 bytes), the host distributes the bytes (any transport: torch.distributed
+ * object broadcast, MPI_Bcast, a file), every rank then calls pvae_comm_init (ncclCommInitRank with the rank / world of
+ * pvae_config; collective).  From then on pvae_train_step / eval_step / grad_step / train_epoch / encode work under
+ * world > 1 exactly as on one GPU: the two SUM all-reduces of a step are enqueued on the engine's stream between the
+ * stages (in place on the exchange buffers; next-batch forward fused as on one GPU).  librccl is bound with dlopen at the
+ * first call, so a process that already holds one (PyTorch's) keeps using that one.  pvae_comm_allreduce runs one such
+ * all-reduce by itself (self-test; host-driven staging).  No counterpart in the reference (it has no multi-GPU path). */
+int pvae_comm_unique_id(char* id128);
+int pvae_comm_init(pvae_engine* e, const char* id128);
+int pvae_comm_allreduce(pvae_engine* e, int which);
+int pvae_comm_destroy(pvae_engine* e);
+
 /* measurement hook: average device time (ms) of the last call's kernels by name, via hipEvents on the
  * engine stream; names: "enc_fwd", "dec", "enc_bwd", "narrow_fwd", "narrow_bwd", "gather" */
 int pvae_set_timing(pvae_engine* e, int enabled);

@@ -20,6 +20,8 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "../../include/pvae.h"
 #include "pvae_kernels.h"
 #include "pvae_narrow.h"
@@ -107,6 +109,9 @@ struct pvae_engine {
     int64_t loss_cap = 0;
     float lr_host = 1e-3f;
     bool has_best = false;
+    // SNP-axis sharding with the engine's own RCCL communicator (pvae_comm_init): the two all-reduces of a step are
+    // enqueued on the engine's stream between the stages, no host code and no cross-stream events in between
+    void* comm = nullptr;
     // staged API: rows whose first-layer partial sums the last pvae_stage_c_next left in encpart (empty = none)
     std::vector<int32_t> promised_rows;
     // pinned host staging ring for the per-step API (rows + eps), so that async copies never read caller memory
@@ -310,6 +315,56 @@ int setup_kernel_attrs(pvae_engine* e) {
 int launch_check(pvae_engine* e, const char* what) {
     hipError_t s = hipGetLastError();
     if (s != hipSuccess) return set_err(e, -11, "launch of %s failed: %s", what, hipGetErrorString(s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL, bound at run time (dlopen: the process may already hold a librccl -- PyTorch ships one -- and must not get a
+// second one; nothing is linked).  Signatures as in rccl.h (ROCm 7.2): ncclUniqueId is 128 opaque bytes passed BY VALUE,
+// ncclFloat32 = 7, ncclSum = 0.
+// ------------------------------------------------------------------------------------------------
+struct PvNcclId { char internal[128]; };
+struct PvRccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(PvNcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, PvNcclId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+PvRccl* rccl() {
+    static PvRccl r;
+    static bool tried = false;
+    if (tried) return &r;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names)  // one that the process already holds (PyTorch's) first
+        if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!r.lib)
+        for (const char* n : names)
+            if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!r.lib) { r.err = std::string("librccl not loadable: ") + dlerror(); return &r; }
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
+        r.err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce / ncclGetErrorString";
+        r.lib = nullptr;
+    }
+    return &r;
+}
+// SUM all-reduce of exchange buffer `which` over the shards, in place, on the engine's stream; nothing to do on one rank
+int shard_allreduce(pvae_engine* e, int which) {
+    if (e->cfg.world == 1 && !e->comm) return 0;  // a one-rank communicator (rehearsal on one GPU) is still driven
+    if (!e->comm) return set_err(e, -5, "world > 1 without a communicator: call pvae_comm_init, or drive the step through "
+                                        "pvae_stage_a/b/c with all-reduces in between");
+    float* buf = which == 0 ? e->P : e->xch1;
+    const size_t n = which == 0 ? (size_t)32 * e->Wp : (size_t)32 * e->Wp + 32;
+    const int rc = rccl()->AllReduce(buf, buf, n, 7 /* ncclFloat32 */, 0 /* ncclSum */, e->comm, e->stream);
+    if (rc) return set_err(e, -12, "ncclAllReduce: %s", rccl()->GetErrorString(rc));
     return 0;
 }
 
@@ -736,21 +791,26 @@ int run_tile(pvae_engine* e, int row_offset, int nrows, int n_batch, int tile, i
     hipLaunchKernelGGL(pvk_tile_begin, dim3(1), dim3(64), 0, e->stream, e->st, nrows, 1.f / (float)n_batch, tile > 0 ? 1 : 0);
     if ((rc = launch_check(e, "tile_begin"))) return rc;
     if ((rc = stage_a(e, row_offset, true))) return rc;
+    if ((rc = shard_allreduce(e, 0))) return rc;
     if ((rc = stage_b(e, mode))) return rc;
+    if ((rc = shard_allreduce(e, 1))) return rc;
     return stage_c(e, mode, d_out3);
 }
 
 int full_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3, int mode) {
     e->promised_rows.clear();
     int rc;
-    if (e->cfg.world != 1)
-        return set_err(e, -5, "world > 1: drive the step through pvae_stage_a/b/c with all-reduces in between");
+    if (e->cfg.world != 1 && !e->comm)
+        return set_err(e, -5, "world > 1: call pvae_comm_init first, or drive the step through pvae_stage_a/b/c with "
+                              "all-reduces in between");
     if (n <= 0 || n > e->cfg.batch_size) return set_err(e, -2, "batch of %d rows (batch_size %d)", n, e->cfg.batch_size);
     if (n <= 32) {
         if ((rc = ensure_loss(e, 1))) return rc;
         if ((rc = begin_batch(e, rows, n, eps, mode == 0))) return rc;
         if ((rc = stage_a(e, 0, true))) return rc;
+        if ((rc = shard_allreduce(e, 0))) return rc;
         if ((rc = stage_b(e, mode))) return rc;
+        if ((rc = shard_allreduce(e, 1))) return rc;
         if ((rc = stage_c(e, mode, e->d_loss))) return rc;
         return fetch_out3(e, out3);
     }
@@ -1024,10 +1084,12 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     return 0;
 }
 
+int pvae_comm_destroy(pvae_engine* e);
 int pvae_destroy(pvae_engine* e) {
     if (!e) return 0;
     hipSetDevice(e->dev);
     if (e->own_stream) hipStreamSynchronize(e->own_stream);
+    pvae_comm_destroy(e);
     for_each_buf(e, [](Buf3& b) { free3(b); });
     for (auto& d : e->enc) { hipFree(d.wf); hipFree(d.wb); }
     for (auto& d : e->dec) { hipFree(d.wf); hipFree(d.wb); }
@@ -1165,7 +1227,7 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
                      float* loss, float* val_loss) {
     e->promised_rows.clear();
     int rc;
-    if (e->cfg.world != 1) return set_err(e, -5, "world > 1: use the staged API");
+    if (e->cfg.world != 1 && !e->comm) return set_err(e, -5, "world > 1: call pvae_comm_init first, or use the staged API");
     if (!e->geno) return set_err(e, -3, "no genotypes loaded (pvae_load_genotypes)");
     if (n_train <= 0) return set_err(e, -2, "empty training set");
     const int B = e->cfg.batch_size;
@@ -1215,7 +1277,9 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
                                phase == 0 ? 1 : 0, e->adam.b1, e->adam.b2, e->eps, 32 * e->K, e->cfg.seed, e->d_counter);
             if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
             if ((rc = stage_a(e, base + s * B, true, fwd_done))) return rc;
+            if ((rc = shard_allreduce(e, 0))) return rc;
             if ((rc = stage_b(e, phase == 0 ? 0 : 1))) return rc;
+            if ((rc = shard_allreduce(e, 1))) return rc;
             if ((rc = stage_c(e, phase == 0 ? 0 : 1, e->d_loss + 3 * ((phase == 0 ? 0 : st_tr) + s), fuse, next_off, next_n)))
                 return rc;
             fwd_done = fuse;
@@ -1255,7 +1319,8 @@ int pvae_encode(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
                 float* z) {
     e->promised_rows.clear();
     int rc;
-    if (e->cfg.world != 1) return set_err(e, -5, "world > 1: use pvae_stage_a + all-reduce + pvae_stage_encode");
+    if (e->cfg.world != 1 && !e->comm)
+        return set_err(e, -5, "world > 1: call pvae_comm_init first, or use pvae_stage_a + all-reduce + pvae_stage_encode");
     const int B = 32;
     for (int i0 = 0; i0 < n; i0 += B) {
         const int nb = std::min(B, n - i0);
@@ -1265,6 +1330,7 @@ int pvae_encode(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
         e->cfg.batch_size = save;
         if (rc) return rc;
         if ((rc = stage_a(e, 0, false))) return rc;
+        if ((rc = shard_allreduce(e, 0))) return rc;
         if ((rc = pvae_stage_encode(e, nb, z_mean ? z_mean + (size_t)i0 * e->K : nullptr,
                                     z_log_var ? z_log_var + (size_t)i0 * e->K : nullptr, z ? z + (size_t)i0 * e->K : nullptr)))
             return rc;
@@ -1446,6 +1512,41 @@ int pvae_stage_c_next(pvae_engine* e, int mode, float* out3, const int32_t* next
     if ((rc = stage_c(e, 0, e->d_loss, true, 32, next_n))) return rc;
     e->promised_rows.assign(next_rows, next_rows + next_n);
     return fetch_out3(e, out3);
+}
+
+int pvae_comm_unique_id(char* id128) {
+    PvRccl* r = rccl();
+    if (!r->lib || !id128) return -12;
+    PvNcclId id;
+    if (r->GetUniqueId(&id)) return -12;
+    memcpy(id128, id.internal, 128);
+    return 0;
+}
+int pvae_comm_init(pvae_engine* e, const char* id128) {
+    PvRccl* r = rccl();
+    if (!r->lib) return set_err(e, -12, "%s", r->err.c_str());
+    if (e->comm) return set_err(e, -12, "communicator already initialised");
+    if (e->cfg.world < 1 || e->cfg.rank < 0 || e->cfg.rank >= e->cfg.world) return set_err(e, -2, "rank %d of %d", e->cfg.rank, e->cfg.world);
+    HIPCHK(hipSetDevice(e->dev));
+    PvNcclId id;
+    memcpy(id.internal, id128, 128);
+    void* comm = nullptr;
+    const int rc = r->CommInitRank(&comm, e->cfg.world, id, e->cfg.rank);
+    if (rc) return set_err(e, -12, "ncclCommInitRank: %s", r->GetErrorString(rc));
+    e->comm = comm;
+    return 0;
+}
+int pvae_comm_allreduce(pvae_engine* e, int which) {
+    if (which != 0 && which != 1) return set_err(e, -2, "exchange buffer %d", which);
+    return shard_allreduce(e, which);
+}
+int pvae_comm_destroy(pvae_engine* e) {
+    if (e->comm) {
+        hipStreamSynchronize(e->stream);
+        rccl()->CommDestroy(e->comm);
+        e->comm = nullptr;
+    }
+    return 0;
 }
 
 int pvae_set_timing(pvae_engine* e, int enabled) {

@@ -4,7 +4,9 @@ The reference has no multi-GPU path (popvae.py:82-89,187 only select a device); 
 SURVEY.md section 8(e) prescribes: rank r owns a contiguous block of SNP columns -- the matching rows of
 the first encoder kernel, columns of the last decoder kernel, output-bias entries, their Adam slots and
 the same columns of the genotype matrix.  The narrow layers are replicated and computed redundantly.
-Per train step there are exactly two small SUM all-reduces:
+Per train step there are exactly two small SUM all-reduces (default: enqueued by the engine itself on its stream through
+its own RCCL communicator, ``pvae_comm_init`` -- no host code inside the step; ``PVAE_COMM=torch`` or a failed
+self-test selects the host-driven staged path over ``torch.distributed`` instead):
 
   1. partial first-layer sums  X_r . W1_r           [32 x width]        (after stage A)
   2. partial decoder feedback  dg_D (and BCE sum)   [32 x width + 32]   (after stage B)
@@ -76,14 +78,54 @@ class ShardedEngine:
                                   batch_size=batch_size, seed=seed, device_id=device_id,
                                   n_snps_global=self.n_snps_global, snp_offset=self.lo, rank=self.rank,
                                   world=self.world, **adam)
+        self.native = self._init_native_comm()
         self._bufs = [self._wrap(*self.eng.exchange_buffer(i), device_id) for i in (0, 1)]
         try:  # test doubles (CPU stand-in engines) take no next_rows
             import inspect
             self._can_fuse = "next_rows" in inspect.signature(self.eng.stage_c).parameters
         except (TypeError, ValueError):
             self._can_fuse = False
-        if hasattr(self.eng, "set_stream") and torch.cuda.is_available():
+        # host-driven exchanges: the engine works on torch's current stream, so that torch.distributed's all-reduces are
+        # ordered with the stages; with its own communicator the engine keeps its own (non-blocking) stream
+        if not self.native and hasattr(self.eng, "set_stream") and torch.cuda.is_available():
             self.eng.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def _init_native_comm(self):
+        """Engine-owned RCCL communicator: rank 0 draws the unique id, torch.distributed carries the 128 bytes, every rank
+        joins, one all-reduce of (rank + 1) on exchange buffer 0 checks the ring, and the ranks agree (MIN over a flag) on
+        using it.  Anything short of that leaves the host-driven path in place."""
+        import os
+        dist = self._dist
+        if os.environ.get("PVAE_COMM", "rccl").lower() == "torch" or not hasattr(self.eng, "comm_init"):
+            return False
+        if not (self.world > 1 or self.force_collectives) or not dist.is_initialized():
+            return False
+        box = [None]
+        if self.rank == 0:
+            try:
+                box[0] = type(self.eng).comm_unique_id()
+            except Exception:
+                box[0] = None
+        dist.broadcast_object_list(box, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+        if box[0] is None:
+            return False
+        ok = 1
+        try:
+            self.eng.comm_init(box[0])
+            n = self.eng.exchange_buffer(0)[1]
+            self.eng.exchange_write(0, np.full(n, self.rank + 1, np.float32))
+            self.eng.comm_allreduce(0)
+            got = self.eng.exchange_read(0)
+            if not np.all(got == np.float32(self.world * (self.world + 1) // 2)):
+                ok = 0
+        except Exception:
+            ok = 0
+        flag = self._torch.tensor([ok], dtype=self._torch.int32)
+        backend = dist.get_backend(self.pg)
+        if backend == "nccl":
+            flag = flag.to(f"cuda:{self._torch.cuda.current_device()}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+        return bool(int(flag.item()))
 
     def _wrap(self, ptr, n, device_id):
         if isinstance(ptr, self._torch.Tensor):  # test doubles hand out CPU tensors directly
@@ -134,6 +176,9 @@ class ShardedEngine:
     def _step(self, rows, eps, mode, want_loss=True, next_rows=None):
         """``next_rows`` (train steps): the batch of the NEXT call, so that its first-layer forward rides on this
         step's wide encoder backward; the partial sums it leaves are all-reduced by the next call as usual."""
+        if self.native:  # the engine runs the whole step, all-reduces included, on its own stream
+            fn = {MODE_TRAIN: self.eng.train_step, MODE_EVAL: self.eng.eval_step}.get(mode)
+            return self.eng.grad_step(rows, eps) if fn is None else fn(rows, eps, want_loss)
         self.eng.stage_a(rows, eps, mode)
         self._allreduce(0)
         self.eng.stage_b(mode)
@@ -162,6 +207,8 @@ class ShardedEngine:
 
     def encode(self, rows, eps=None):
         rows = np.ascontiguousarray(rows, dtype=np.int32)
+        if self.native:
+            return self.eng.encode(rows, eps)
         outs = []
         for i0 in range(0, len(rows), 32):
             r = rows[i0:i0 + 32]
@@ -192,6 +239,8 @@ class ShardedEngine:
         B = self.batch_size
         perm = np.ascontiguousarray(perm, dtype=np.int32)
         val_rows = np.ascontiguousarray(val_rows, dtype=np.int32)
+        if self.native and eps_fn is None:  # the C-side epoch loop, as on one GPU
+            return self.eng.train_epoch(perm, val_rows)
         tl, vl = [], []
         fuse = B <= 32
         for i0 in range(0, len(perm), B):

@@ -21,6 +21,7 @@ ENGINE_SYMBOLS = [
     "pvae_train_step", "pvae_eval_step", "pvae_grad_step", "pvae_get_grad", "pvae_train_epoch", "pvae_encode",
     "pvae_decode", "pvae_pca_gram", "pvae_snapshot_best", "pvae_restore_best", "pvae_exchange_buffer", "pvae_exchange_copy", "pvae_stage_a", "pvae_stage_b",
     "pvae_stage_c", "pvae_stage_c_next", "pvae_stage_encode", "pvae_set_timing", "pvae_get_timing", "pvae_set_timing_only",
+    "pvae_comm_unique_id", "pvae_comm_init", "pvae_comm_allreduce", "pvae_comm_destroy",
 ]
 
 
@@ -84,6 +85,10 @@ def lib():
         L.pvae_stage_encode.argtypes = [vp, i32, _fopt, _fopt, _fopt]
         L.pvae_set_timing.argtypes = [vp, C.c_int]
         L.pvae_set_timing_only.argtypes = [vp, C.c_char_p]
+        L.pvae_comm_unique_id.argtypes = [C.c_char_p]
+        L.pvae_comm_init.argtypes = [vp, C.c_char_p]
+        L.pvae_comm_allreduce.argtypes = [vp, C.c_int]
+        L.pvae_comm_destroy.argtypes = [vp]
         L.pvae_get_timing.argtypes = [vp, C.c_char_p, _fopt, C.POINTER(i64)]
         _lib = L
     return _lib
@@ -308,6 +313,24 @@ class Engine:
         mu, lv, z = (np.zeros((n, K), np.float32) for _ in range(3))
         self._ck(lib().pvae_stage_encode(self._h, n, _fptr(mu), _fptr(lv), _fptr(z)))
         return mu, lv, z
+
+    # -- engine-owned RCCL communicator (SNP-axis sharding with no host code inside the step) ------
+    @staticmethod
+    def comm_unique_id():
+        """ncclGetUniqueId on this rank: 128 bytes for the host to hand to every rank's ``comm_init``."""
+        buf = C.create_string_buffer(128)
+        rc = lib().pvae_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError("pvae_comm_unique_id failed: librccl not loadable?")
+        return buf.raw
+
+    def comm_init(self, id128):
+        if len(id128) != 128:
+            raise ValueError("a RCCL unique id is 128 bytes")
+        self._ck(lib().pvae_comm_init(self._h, id128))
+
+    def comm_allreduce(self, which):
+        self._ck(lib().pvae_comm_allreduce(self._h, which))
 
     # -- measurement -----------------------------------------------------------------------------
     def set_timing(self, on, only=None):

@@ -1,0 +1,44 @@
+"""Child process of tests/test_gpu_comm.py: the engine's own RCCL communicator with ONE rank on the test box's GPU, in the
+library order of real use (torch first: popvae_amd.dist / bench.py import it before the engine, so PyTorch's librccl and HIP
+runtime are the ones in the process).  Prints OK and exits 0 when the communicator path equals the plain engine bit for bit."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402,F401
+
+torch.cuda.init()
+import numpy as np  # noqa: E402
+
+from popvae_amd import engine, prep  # noqa: E402
+from tests.test_gpu_parity import _problem  # noqa: E402
+
+N, L, W, D, K = 80, 3000, 128, 3, 2
+dc, w = _problem(N, L, W, D, K, seed=31)
+g = np.random.default_rng(3)
+perm = g.permutation(70).astype(np.int32)
+val = np.arange(70, 80, dtype=np.int32)
+outs = []
+for with_comm in (False, True):
+    e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=32, seed=5)
+    if with_comm:
+        e.comm_init(engine.Engine.comm_unique_id())
+        n = e.exchange_buffer(0)[1]
+        e.exchange_write(0, np.arange(n, dtype=np.float32))
+        e.comm_allreduce(0)  # a one-rank SUM is the identity
+        assert np.array_equal(e.exchange_read(0), np.arange(n, dtype=np.float32))
+    e.load_genotypes(prep.pack_dc(dc))
+    e.set_weights([x.astype(np.float32) for x in w])
+    res = [e.train_epoch(perm, val) for _ in range(2)]
+    res.append(e.train_step(perm[:32]))
+    res.append(e.eval_step(val))
+    mu, _, _ = e.encode(np.arange(N, dtype=np.int32))
+    outs.append((res, e.get_weights(), mu))
+    e.close()
+(ra, wa, ma), (rb, wb, mb) = outs
+assert ra == rb, (ra, rb)
+for a, b in zip(wa, wb):
+    assert np.array_equal(a, b)
+assert np.array_equal(ma, mb)
+print("OK", flush=True)
