@@ -175,8 +175,6 @@ def _init_pg(rank, world, port, backend="gloo"):
 def sharded_worker(rank, world, port, out_path, use_gpu, dims):
     """Runs the sharded protocol (ShardedEngine) on one rank and saves what the parent test compares."""
     sys.path.insert(0, ROOT)
-    # ranks that share one GPU cannot form a RCCL communicator (one rank per device): host-driven exchanges over gloo
-    os.environ["PVAE_COMM"] = "torch"
     dist = _init_pg(rank, world, port)
     from popvae_amd.dist import ShardedEngine
     N, L, W, D, K = dims

@@ -9,9 +9,13 @@ from tests import dist_helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dims", [(40, 1000, 128, 3, 2), (40, 700, 256, 2, 2)])
-def test_two_rank_snp_sharding_on_one_gpu(tmp_path, dims):
+@pytest.mark.parametrize("dims,comm", [((40, 1000, 128, 3, 2), "rccl"), ((40, 700, 256, 2, 2), "torch")])
+def test_two_rank_snp_sharding_on_one_gpu(tmp_path, monkeypatch, dims, comm):
+    """comm = "torch": host-driven exchanges from the start.  comm = "rccl": the ranks first try the engine-owned RCCL
+    communicator -- unique id broadcast, both enter ncclCommInitRank, RCCL refuses two ranks on one device -- and must
+    then AGREE on falling back to the host-driven path (the bootstrap and the agreed fallback are what is tested here)."""
     import torch.multiprocessing as mp
+    monkeypatch.setenv("PVAE_COMM", comm)
     out = str(tmp_path / "res")
     port = 29500 + int(np.random.default_rng().integers(0, 2000))
     mp.spawn(H.sharded_worker, args=(2, port, out, True, dims), nprocs=2, join=True)
