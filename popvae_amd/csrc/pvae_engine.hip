@@ -87,6 +87,8 @@ struct pvae_engine {
     float *dA = nullptr, *dB = nullptr, *dpre1 = nullptr, *dheads = nullptr, *dz = nullptr;
     uint64_t* Xt = nullptr;
     float* probs = nullptr;  // decoder.predict staging [32][L], allocated on first pvae_decode
+    float* enc_out = nullptr;  // encoder.predict staging: per 32-row batch [32][Kh] heads + [32][Kz] z, read back once
+    int64_t enc_out_cap = 0;   // in batches
     // scratch
     float *encpart = nullptr, *dgpart = nullptr, *losspart = nullptr;
     int enc_wgs = 0, dec_wgs = 0, encb_wgs = 0;
@@ -1102,6 +1104,7 @@ int pvae_destroy(pvae_engine* e) {
     hipFree(e->d_fwd_ops); hipFree(e->d_bwd_ops); hipFree(e->d_bwd_ops_grad);
     for (auto p : e->dpre_bufs) hipFree(p);
     hipFree(e->probs);
+    hipFree(e->enc_out);
     hipFree(e->Xt); hipFree(e->geno); hipFree(e->st); hipFree(e->d_rows); hipFree(e->d_ntotal); hipFree(e->d_counter);
     for (auto& ev : e->evs) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     for (auto& sl : e->slots) { if (sl.host) hipHostFree(sl.host); if (sl.ev) hipEventDestroy(sl.ev); }
@@ -1321,9 +1324,21 @@ int pvae_encode(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
     int rc;
     if (e->cfg.world != 1 && !e->comm)
         return set_err(e, -5, "world > 1: call pvae_comm_init first, or use pvae_stage_a + all-reduce + pvae_stage_encode");
-    const int B = 32;
-    for (int i0 = 0; i0 < n; i0 += B) {
-        const int nb = std::min(B, n - i0);
+    if (n <= 0) return set_err(e, -2, "encode of %d rows", n);
+    const int B = 32, nbat = (n + B - 1) / B;
+    // the batches are queued back to back; their outputs collect in a device staging buffer and come back in ONE copy
+    // (a device-to-host round trip per batch left the GPU idle for longer than a batch takes)
+    const size_t per = (size_t)32 * (e->Kh + e->Kz);
+    if (nbat > e->enc_out_cap) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->enc_out) hipFree(e->enc_out);
+        e->enc_out = nullptr;
+        e->enc_out_cap = 0;
+        HIPCHK(hipMalloc(&e->enc_out, (size_t)nbat * per * sizeof(float)));
+        e->enc_out_cap = nbat;
+    }
+    for (int i = 0; i < nbat; ++i) {
+        const int i0 = i * B, nb = std::min(B, n - i0);
         const int save = e->cfg.batch_size;
         e->cfg.batch_size = 32;  // predict batches are independent of the training batch size
         rc = begin_batch(e, rows + i0, nb, eps ? eps + (size_t)i0 * e->K : nullptr, false);
@@ -1331,9 +1346,22 @@ int pvae_encode(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
         if (rc) return rc;
         if ((rc = stage_a(e, 0, false))) return rc;
         if ((rc = shard_allreduce(e, 0))) return rc;
-        if ((rc = pvae_stage_encode(e, nb, z_mean ? z_mean + (size_t)i0 * e->K : nullptr,
-                                    z_log_var ? z_log_var + (size_t)i0 * e->K : nullptr, z ? z + (size_t)i0 * e->K : nullptr)))
-            return rc;
+        if ((rc = narrow_encoder(e))) return rc;
+        float* dst = e->enc_out + (size_t)i * per;
+        HIPCHK(hipMemcpyAsync(dst, e->headout, (size_t)32 * e->Kh * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(dst + 32 * e->Kh, e->z, (size_t)32 * e->Kz * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    }
+    std::vector<float> host((size_t)nbat * per);
+    HIPCHK(hipMemcpyAsync(host.data(), e->enc_out, host.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int r = 0; r < n; ++r) {
+        const float* ho = host.data() + (size_t)(r / B) * per + (size_t)(r % B) * e->Kh;
+        const float* zz = host.data() + (size_t)(r / B) * per + (size_t)32 * e->Kh + (size_t)(r % B) * e->Kz;
+        for (int k = 0; k < e->K; ++k) {
+            if (z_mean) z_mean[(size_t)r * e->K + k] = ho[k];
+            if (z_log_var) z_log_var[(size_t)r * e->K + k] = ho[e->K + k];
+            if (z) z[(size_t)r * e->K + k] = zz[k];
+        }
     }
     return 0;
 }
