@@ -261,7 +261,20 @@ __global__ __launch_bounds__(256) void pvk_dense_fwd(const float* __restrict__ i
     float* red = smem + 32 * (K + 1);    // [4][16][64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.x * 32;
-    for (int i = tid; i < 32 * K; i += 256) in_s[(i / K) * (K + 1) + (i % K)] = in[i];
+    // 16-byte loads, 4 in flight per thread (K is a multiple of 32, so a float4 never straddles a row)
+    for (int i0 = tid; i0 < 8 * K; i0 += 1024) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const f32x4*>(in)[min(i0 + 256 * u, 8 * K - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = 4 * (i0 + 256 * u);
+            if (i < 32 * K) {
+                float* d = in_s + (i / K) * (K + 1) + (i % K);
+                d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+            }
+        }
+    }
     __syncthreads();
     f32x16 acc;
 #pragma unroll
@@ -282,7 +295,11 @@ __global__ __launch_bounds__(256) void pvk_dense_fwd(const float* __restrict__ i
             for (int s = 0; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
         }
     };
-    if (kper % 32 == 0) run(std::integral_constant<int, 16>{});
+    // widths 512 / 256: the wave's whole k range in ONE group -- every weight load of the layer is in flight before the
+    // first MFMA, one L2 round trip per layer instead of one per 16 steps
+    if (kper == 128) run(std::integral_constant<int, 64>{});
+    else if (kper == 64) run(std::integral_constant<int, 32>{});
+    else if (kper % 32 == 0) run(std::integral_constant<int, 16>{});
     else run(std::integral_constant<int, 4>{});
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
@@ -315,25 +332,31 @@ __global__ __launch_bounds__(256) void pvk_dense_bwd(int K, const float* __restr
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int k0 = blockIdx.x * 32;
     const int nrows = st->nrows;
-    for (int i0 = tid; i0 < 32 * N; i0 += 1024) {
-        float yv[4], dv[4], wv[4];
+    // 16-byte loads, 4 x 3 in flight per thread (N is a multiple of 32, so a float4 never straddles a row)
+    for (int i0 = tid; i0 < 8 * N; i0 += 1024) {
+        f32x4 yv[4], dv[4], wv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {  // loads of 4 iterations in flight together
-            const int i = i0 + u * 256;
+        for (int u = 0; u < 4; ++u) {
+            const int i4 = min(i0 + 256 * u, 8 * N - 1), i = 4 * i4;
             const int b = i / N, n = i % N;
-            dv[u] = dY[i];
-            yv[u] = act == PV_ACT_ELU ? Y[i] : 1.f;
-            wv[u] = Wt[(int64_t)(k0 + b) * N + n];
+            dv[u] = reinterpret_cast<const f32x4*>(dY)[i4];
+            if (act == PV_ACT_ELU) yv[u] = reinterpret_cast<const f32x4*>(Y)[i4];
+            wv[u] = *reinterpret_cast<const f32x4*>(Wt + (int64_t)(k0 + b) * N + n);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 256;
-            const int b = i / N, n = i % N;
-            float d = b < nrows ? dv[u] : 0.f;
-            if (act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[u]);
-            dp_s[b * ld + n] = d;
-            w_s[b * ld + n] = wv[u];
-            if (blockIdx.x == 0) dpre_out[i] = d;
+            const int i = 4 * (i0 + 256 * u);
+            if (i < 32 * N) {
+                const int b = i / N, n = i % N;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d = b < nrows ? dv[u][e] : 0.f;
+                    if (act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[u][e]);
+                    dp_s[b * ld + n + e] = d;
+                    w_s[b * ld + n + e] = wv[u][e];
+                    if (blockIdx.x == 0) dpre_out[i + e] = d;
+                }
+            }
         }
     }
     __syncthreads();
