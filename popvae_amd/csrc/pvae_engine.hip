@@ -1276,10 +1276,12 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
                 if (s + 1 < st_tr) { next_off = (s + 1) * B; next_n = std::min(B, n_train - next_off); fuse = true; }
                 else if (st_va > 0) { next_off = n_train; next_n = std::min(B, (int)n_val); fuse = true; }
             }
-            hipLaunchKernelGGL(pvk_step_begin_eps, dim3(1), dim3(1024), 0, e->stream, e->st, (const int*)e->d_ntotal, 0, B, s,
-                               phase == 0 ? 1 : 0, e->adam.b1, e->adam.b2, e->eps, 32 * e->K, e->cfg.seed, e->d_counter);
-            if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
-            if ((rc = stage_a(e, base + s * B, true, fwd_done))) return rc;
+            // per-step scalars + noise + batch gather in one launch
+            hipLaunchKernelGGL(pvk_step_begin_gather, dim3(((e->nblk + 1) / 2 + 3) / 4 + 1), dim3(256), 0, e->stream, e->st,
+                               (const int*)e->d_ntotal, B, s, phase == 0 ? 1 : 0, e->adam.b1, e->adam.b2, e->eps, 32 * e->K,
+                               e->cfg.seed, e->d_counter, e->geno, e->row_bytes, (const int*)e->d_rows, base + s * B, e->nblk, e->Xt);
+            if ((rc = launch_check(e, "step_begin/gen_eps/gather"))) return rc;
+            if ((rc = stage_a(e, base + s * B, false, fwd_done))) return rc;
             if ((rc = shard_allreduce(e, 0))) return rc;
             if ((rc = stage_b(e, phase == 0 ? 0 : 1))) return rc;
             if ((rc = shard_allreduce(e, 1))) return rc;
