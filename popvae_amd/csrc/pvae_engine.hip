@@ -944,8 +944,6 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
         return bail(set_err(e, -2, "bad dimensions"));
     if (cfg->batch_size < 1 || cfg->batch_size > 65536)
         return bail(set_err(e, -2, "batch_size %d unsupported (1..65536)", cfg->batch_size));
-    if (cfg->batch_size > 32 && cfg->world > 1)
-        return bail(set_err(e, -2, "batch_size %d with SNP-axis sharding: the staged API handles 1..32 rows per step", cfg->batch_size));
     if (cfg->width > 512) return bail(set_err(e, -2, "width %d unsupported: this build handles widths up to 512", cfg->width));
     if (cfg->latent_dim > 16) return bail(set_err(e, -2, "latent_dim %d unsupported (max 16)", cfg->latent_dim));
     int ndev = 0;

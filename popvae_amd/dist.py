@@ -179,6 +179,9 @@ class ShardedEngine:
         if self.native:  # the engine runs the whole step, all-reduces included, on its own stream
             fn = {MODE_TRAIN: self.eng.train_step, MODE_EVAL: self.eng.eval_step}.get(mode)
             return self.eng.grad_step(rows, eps) if fn is None else fn(rows, eps, want_loss)
+        if len(rows) > 32:
+            raise ValueError(f"batch of {len(rows)} rows under SNP-axis sharding: the host-driven staged path moves one 32-row "
+                             "tile per exchange; batches above 32 rows need the engine-owned communicator (PVAE_COMM=rccl)")
         self.eng.stage_a(rows, eps, mode)
         self._allreduce(0)
         self.eng.stage_b(mode)
