@@ -107,6 +107,9 @@ def main():
                          "NaN run is not a fair timing, so the bench steps at 1e-4; throughput does not depend on it")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
+    if os.environ.get("PVAE_BENCH_TRACE"):  # debugging aid: Python stacks of a stuck rank every N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PVAE_BENCH_TRACE"]), repeat=True)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -119,11 +122,20 @@ def main():
     from popvae_amd import engine as E
     from popvae_amd.dist import ShardedEngine, shard_bounds, shard_packed
 
+    # PVAE_BENCH_BACKEND=gloo: rehearsal of the N > 1 host code with several ranks sharing the GPUs that are there (RCCL
+    # refuses two ranks on one device, so the ranks agree on the host-driven exchange path); never a measurement
+    backend = os.environ.get("PVAE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
+        os.environ.setdefault("PVAE_COMM", "torch")  # two ranks on one device: RCCL cannot form the communicator
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     sharded = world > 1 or args.force_sharded
     if world > 1 or (args.force_sharded and "RANK" in os.environ):
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
     L, W, D, K, B, N = wl["n_snps"], wl["width"], wl["depth"], wl["latent_dim"], wl["batch"], wl["n_samples"]
     lo, hi = shard_bounds(L, world)[rank]
@@ -158,8 +170,9 @@ def main():
             # C-side loop: exactly len(rows2d) train steps, no validation rows
             losses.append(eng.train_epoch(rows2d.reshape(-1), np.zeros(0, np.int32))[0])
         else:
+            nofuse, sync = os.environ.get("PVAE_BENCH_NOFUSE"), bool(os.environ.get("PVAE_BENCH_SYNC"))  # debugging aids
             for k in range(len(rows2d) - 1):  # the next batch is known: its first-layer forward rides on this step
-                step_engine._step(rows2d[k], None, E.MODE_TRAIN, want_loss=False, next_rows=rows2d[k + 1])
+                step_engine._step(rows2d[k], None, E.MODE_TRAIN, want_loss=sync, next_rows=None if nofuse else rows2d[k + 1])
             losses.append(step_engine._step(rows2d[-1], None, E.MODE_TRAIN, want_loss=True)[0])
 
     def barrier():
@@ -182,7 +195,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     dec_timed = eng.get_timing("dec")
@@ -248,7 +261,7 @@ def main():
             "metric": "train_samples_per_sec", "value": args.steps * B / elapsed, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if backend == "nccl" else f"synthetic; REHEARSAL over {backend}, ranks share GPUs: not a measurement",
             "config": {"workload": f"{args.workload}: {N} samples x {L} SNPs, depth {D}, width {W}, latent {K}, "
                                    f"batch {B}, fp32 weights + fused Keras-Adam (lr {args.lr:g})",
                        "parallelism": (f"snp-shard x{world}, " + ("all-reduces enqueued by the engine (own RCCL communicator)"

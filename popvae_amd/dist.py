@@ -78,6 +78,12 @@ class ShardedEngine:
                                   batch_size=batch_size, seed=seed, device_id=device_id,
                                   n_snps_global=self.n_snps_global, snp_offset=self.lo, rank=self.rank,
                                   world=self.world, **adam)
+        import os
+        self._trace = bool(os.environ.get("PVAE_DIST_TRACE"))  # debugging aid: progress line around every host-driven exchange
+        # host-driven exchanges are bracketed by host syncs (see _allreduce); PVAE_DIST_STREAM_ORDERED=1 selects the
+        # stream-ordered variant under RCCL (engine on torch's current stream, no host sync inside a step)
+        self._host_sync = dist.is_initialized() and not (dist.get_backend(process_group) == "nccl"
+                                                         and os.environ.get("PVAE_DIST_STREAM_ORDERED"))
         self.native = self._init_native_comm()
         self._bufs = [self._wrap(*self.eng.exchange_buffer(i), device_id) for i in (0, 1)]
         try:  # test doubles (CPU stand-in engines) take no next_rows
@@ -85,10 +91,15 @@ class ShardedEngine:
             self._can_fuse = "next_rows" in inspect.signature(self.eng.stage_c).parameters
         except (TypeError, ValueError):
             self._can_fuse = False
-        # host-driven exchanges: the engine works on torch's current stream, so that torch.distributed's all-reduces are
-        # ordered with the stages; with its own communicator the engine keeps its own (non-blocking) stream
+        # host-driven exchanges: with its own communicator the engine keeps its own (non-blocking) stream and torch is not
+        # involved in a step at all.  Otherwise the exchanges never touch torch's legacy default stream (its implicit synchronisation with every blocking stream
+        # of the process is what the dead-lock described in _allreduce hinged on): they run on a dedicated non-blocking torch
+        # stream, which is also the engine's stream in the stream-ordered variant.
+        self._xs = None
         if not self.native and hasattr(self.eng, "set_stream") and torch.cuda.is_available():
-            self.eng.set_stream(torch.cuda.current_stream().cuda_stream)
+            self._xs = torch.cuda.Stream(device=device_id)
+            if not self._host_sync:
+                self.eng.set_stream(self._xs.cuda_stream)
 
     def _init_native_comm(self):
         """Engine-owned RCCL communicator: rank 0 draws the unique id, torch.distributed carries the 128 bytes, every rank
@@ -134,7 +145,25 @@ class ShardedEngine:
 
     def _allreduce(self, which):
         if self.world > 1 or self.force_collectives:
-            self._dist.all_reduce(self._bufs[which], op=self._dist.ReduceOp.SUM, group=self.pg)
+            if self._trace:
+                self._n_ar = getattr(self, "_n_ar", 0) + 1
+                print(f"[dist r{self.rank}] all_reduce #{self._n_ar} buf {which} enter", flush=True)
+            # torch.distributed runs a collective on side streams tied to the current stream by events (gloo adds a worker
+            # thread and host staging).  With engine kernels still queued ahead of the exchange on torch's legacy default
+            # stream this was seen to dead-lock after a few steps (two ranks on one GPU over gloo), so by default the engine
+            # keeps its own stream and every exchange is bracketed by host syncs: this is the fallback path, a few tens of
+            # microseconds per exchange matter less than a hang.
+            if self._host_sync:
+                self.eng.synchronize()
+            if self._xs is not None:
+                with self._torch.cuda.stream(self._xs):
+                    self._dist.all_reduce(self._bufs[which], op=self._dist.ReduceOp.SUM, group=self.pg)
+                if self._host_sync:
+                    self._xs.synchronize()
+            else:
+                self._dist.all_reduce(self._bufs[which], op=self._dist.ReduceOp.SUM, group=self.pg)
+            if self._trace:
+                print(f"[dist r{self.rank}] all_reduce #{self._n_ar} done", flush=True)
 
     # -- data / weights ------------------------------------------------------------------------
     def load_genotypes(self, packed_full):
