@@ -79,11 +79,14 @@ class ShardedEngine:
                                   n_snps_global=self.n_snps_global, snp_offset=self.lo, rank=self.rank,
                                   world=self.world, **adam)
         import os
+        self.device_id = int(device_id)
         self._trace = bool(os.environ.get("PVAE_DIST_TRACE"))  # debugging aid: progress line around every host-driven exchange
         # host-driven exchanges are bracketed by host syncs (see _allreduce); PVAE_DIST_STREAM_ORDERED=1 selects the
         # stream-ordered variant under RCCL (engine on torch's current stream, no host sync inside a step)
         self._host_sync = dist.is_initialized() and not (dist.get_backend(process_group) == "nccl"
                                                          and os.environ.get("PVAE_DIST_STREAM_ORDERED"))
+        self._host_staged = (dist.is_initialized() and dist.get_backend(process_group) != "nccl"
+                             and hasattr(self.eng, "exchange_read"))
         self.native = self._init_native_comm()
         self._bufs = [self._wrap(*self.eng.exchange_buffer(i), device_id) for i in (0, 1)]
         try:  # test doubles (CPU stand-in engines) take no next_rows
@@ -110,6 +113,21 @@ class ShardedEngine:
         if os.environ.get("PVAE_COMM", "rccl").lower() == "torch" or not hasattr(self.eng, "comm_init"):
             return False
         if not (self.world > 1 or self.force_collectives) or not dist.is_initialized():
+            return False
+        # RCCL wants one device per rank: two ranks on one GPU (tests, rehearsals) would fail inside ncclCommInitRank and leave
+        # half-built communicator state behind (later collectives of the process were seen to hang), so the ranks compare
+        # device identities first and do not try
+        import socket
+        dev = self.device_id
+        try:
+            uid = str(self._torch.cuda.get_device_properties(self._torch.cuda.current_device() if dev is None else dev).uuid)
+        except Exception:
+            uid = None
+        ident = (socket.gethostname(), uid, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"),
+                 self._torch.cuda.current_device() if dev is None else dev)
+        idents = [None] * self.world
+        dist.all_gather_object(idents, ident, group=self.pg)
+        if len(set(idents)) < self.world:
             return False
         box = [None]
         if self.rank == 0:
@@ -153,6 +171,16 @@ class ShardedEngine:
             # stream this was seen to dead-lock after a few steps (two ranks on one GPU over gloo), so by default the engine
             # keeps its own stream and every exchange is bracketed by host syncs: this is the fallback path, a few tens of
             # microseconds per exchange matter less than a hang.
+            # Backends without device-pointer support of their own (gloo) get host buffers: pvae_exchange_copy stages the
+            # exchange buffer through the host (synchronous on the engine's stream), the collective runs on CPU tensors.
+            # gloo's own staging of CUDA tensors hung intermittently here even with the engine idle.
+            if self._host_staged:
+                h = self._torch.from_numpy(self.eng.exchange_read(which))
+                self._dist.all_reduce(h, op=self._dist.ReduceOp.SUM, group=self.pg)
+                self.eng.exchange_write(which, h.numpy())
+                if self._trace:
+                    print(f"[dist r{self.rank}] all_reduce #{self._n_ar} done (host-staged)", flush=True)
+                return
             if self._host_sync:
                 self.eng.synchronize()
             if self._xs is not None:
@@ -256,7 +284,7 @@ class ShardedEngine:
         if self.world > 1 or self.force_collectives:
             t = self._torch.from_numpy(G)
             dev = self._bufs[0].device if isinstance(self._bufs[0], self._torch.Tensor) else "cpu"
-            if str(dev) != "cpu":
+            if str(dev) != "cpu" and not self._host_staged:
                 t = t.to(dev)
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.pg)
             G = t.cpu().numpy()

@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("dims,comm", [((40, 1000, 128, 3, 2), "rccl"), ((40, 700, 256, 2, 2), "torch")])
 def test_two_rank_snp_sharding_on_one_gpu(tmp_path, monkeypatch, dims, comm):
-    """comm = "torch": host-driven exchanges from the start.  comm = "rccl": the ranks first try the engine-owned RCCL
-    communicator -- unique id broadcast, both enter ncclCommInitRank, RCCL refuses two ranks on one device -- and must
-    then AGREE on falling back to the host-driven path (the bootstrap and the agreed fallback are what is tested here)."""
+    """comm = "torch": host-driven exchanges from the start.  comm = "rccl": the ranks first consider the engine-owned RCCL
+    communicator, find that they share a device (RCCL wants one per rank; a doomed ncclCommInitRank would leave half-built
+    state behind) and must AGREE on the host-driven path -- the agreement is what is tested here."""
     import torch.multiprocessing as mp
     monkeypatch.setenv("PVAE_COMM", comm)
     out = str(tmp_path / "res")
