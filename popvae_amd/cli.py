@@ -156,8 +156,16 @@ def main(argv=None):
     if world > 1:
         import torch
         import torch.distributed as dist
+        # PVAE_DIST_BACKEND=gloo: several ranks on the GPUs that are there (tests / rehearsals on a one-GPU box)
+        backend = os.environ.get("PVAE_DIST_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank %= max(1, torch.cuda.device_count())
+            device_id = local_rank
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
     seed = args.seed
     if seed is not None:

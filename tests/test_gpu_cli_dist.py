@@ -1,0 +1,69 @@
+"""popvae.py end to end under SNP-axis sharding: two ranks sharing the test box's GPU (launched exactly as on a node, through
+torch.distributed.run; PVAE_DIST_BACKEND=gloo lets them share the device, the exchanges are host-staged) against the same
+command on one rank -- same seed, so the split, the shuffles and the noise agree and only the summation order of the two
+exchange points differs.  Also the --search_network_sizes grid spread over the ranks (one network per rank, results
+gathered in the reference's row order).  RCCL between distinct devices is what bench.py --gpus N exercises."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+VCF = os.path.join(HERE, "golden", "pabu_test_genotypes.vcf.gz")
+
+
+def _run(cmd, env=None, timeout=280):
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, (cmd, p.stdout[-1500:], p.stderr[-3000:])
+    return p
+
+
+def _launch2(args, port):
+    env = dict(os.environ, PVAE_DIST_BACKEND="gloo")
+    return _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                 "127.0.0.1", "--master-port", str(port), "popvae.py"] + args, env=env)
+
+
+def _table(path):
+    rows = [l.rstrip("\n").split("\t") for l in open(path)]
+    return rows[0], rows[1:]
+
+
+def test_two_rank_cli_matches_one_rank(tmp_path):
+    common = ["--infile", VCF, "--seed", "42", "--max_epochs", "25", "--patience", "10"]
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    _run([sys.executable, "popvae.py", "--out", one] + common)
+    port = 29600 + int(np.random.default_rng().integers(0, 2000))
+    _launch2(["--out", two, "--PCA"] + common, port)
+    h1, a = _table(one + "_latent_coords.txt")
+    h2, b = _table(two + "_latent_coords.txt")
+    assert h1 == h2 == ["mean1", "mean2", "sd1", "sd2", "sampleID"]
+    assert [r[-1] for r in a] == [r[-1] for r in b] and len(a) == 95
+    A = np.array([[float(x) for x in r[:4]] for r in a])
+    B = np.array([[float(x) for x in r[:4]] for r in b])
+    # float32 re-association at the two exchange points, amplified over 25 epochs x 3 steps of Adam
+    assert np.abs(A - B).max() <= 2e-3 * max(1.0, np.abs(A).max()), np.abs(A - B).max()
+    H1 = np.loadtxt(one + "_history.txt", skiprows=1)
+    H2 = np.loadtxt(two + "_history.txt", skiprows=1)
+    assert H1.shape == H2.shape and H1.shape[1] == 4
+    assert np.allclose(H1, H2, rtol=1e-4)
+    for suffix in ("_training_preds.txt", "_pca.txt", "_runtimes.txt"):
+        assert os.path.getsize(two + suffix) > 0
+    assert len(open(two + "_pca.txt").read().splitlines()) == 96
+
+
+def test_two_rank_grid_search(tmp_path):
+    out = str(tmp_path / "grid")
+    port = 29600 + int(np.random.default_rng().integers(0, 2000))
+    _launch2(["--infile", VCF, "--out", out, "--seed", "42", "--max_epochs", "8", "--patience", "4", "--search_network_sizes",
+              "--width_range", "32,64", "--depth_range", "2,3"], port)
+    rows = open(out + "_param_grid.csv").read().splitlines()
+    assert rows[0] == "width,depth,val_loss"
+    assert [r.split(",")[:2] for r in rows[1:]] == [["32", "2"], ["32", "3"], ["64", "2"], ["64", "3"]]  # width-major
+    assert all(np.isfinite(float(r.split(",")[2])) for r in rows[1:])
+    assert os.path.getsize(out + "_latent_coords.txt") > 0
