@@ -284,8 +284,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, packed, lr=args.lr)
         print(json.dumps(out), flush=True)
+    # orderly teardown: the engine (and with it its RCCL communicator) goes first, on every rank, then torch's process group
+    eng.synchronize()
     if dist.is_initialized():
         dist.barrier()
+    step_engine.close()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
