@@ -121,12 +121,14 @@ def test_epoch_loop_equals_stepwise_at_full_size(L, W, D):
         assert np.abs(a - b).max() <= 1e-6, (i, np.abs(a - b).max())
 
 
-def test_snp_shards_add_up_at_full_size():
-    """Linearity of the two exchange points at 1M SNPs: two engines holding half of the SNP axis each, driven
+@pytest.mark.parametrize("L,D", [(1_000_000, 6), (4_000_031, 3)])
+def test_snp_shards_add_up_at_full_size(L, D):
+    """Linearity of the two exchange points at 1M SNPs and at 4M + 31 SNPs (four times the headline shape, ragged last
+    block: 64-bit tile offsets, 2 GB per wide tensor): two engines holding half of the SNP axis each, driven
     through the staged C ABI with the host adding their exchange buffers (pvae_exchange_copy), reproduce the unsharded loss and
     the unsharded gradients (wide tensors: the matching slices)."""
     from popvae_amd.dist import shard_bounds, shard_packed
-    L, W, D, K, N, n = 1_000_000, 128, 6, 2, 40, 32
+    W, K, N, n = 128, 2, 40, 32
     codes = _codes(N, L, seed=11)
     packed = _pack(codes)
     g = np.random.default_rng(2)
@@ -164,7 +166,8 @@ def test_snp_shards_add_up_at_full_size():
     exchange(1)
     outs = [e.stage_c(engine.MODE_GRAD, True) for e in engs]
     assert outs[0] == outs[1]
-    assert abs(outs[0][0] - loss) <= 1e-6 * abs(loss), (outs[0][0], loss)
+    # float32 sums of L x 32 BCE terms in two different orders (per-lane partials, then workgroups, then shards)
+    assert abs(outs[0][0] - loss) <= 1e-5 * abs(loss), (outs[0][0], loss)
     for r, ((lo, hi), e) in enumerate(zip(bounds, engs)):
         gs = e.get_grads()
         ref = list(gf)
