@@ -224,6 +224,19 @@ def main():
     torch.cuda.synchronize()
     val_ms = (time.perf_counter() - t1) * 1e3 / n_val_steps
 
+    # ---- whole epochs as popvae.py runs them: one C-side call = 90 % of the samples in shuffled batches + the validation
+    # batches (K8/K9), three in a row; untimed in `value` ----
+    epoch_ms = None
+    if not sharded or native:
+        n_tr = int(0.9 * N)
+        ep = [(g.permutation(N)[:n_tr].astype(np.int32), np.arange(n_tr, N, dtype=np.int32)) for _ in range(3)]
+        barrier()
+        t2 = time.perf_counter()
+        for perm, val in ep:
+            eng.train_epoch(perm, val)
+        eng.synchronize()
+        epoch_ms = (time.perf_counter() - t2) * 1e3 / len(ep)
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         Ll = hi - lo
@@ -274,7 +287,10 @@ def main():
                          "avg_launch_ms": kernels.get("dec", {}).get("ms")},
             "kernels": kernels,
             "kernels_note": "dec: HIP events over the timed region; the others: a separate untimed pass of 20 steps",
-            "epochs_per_sec": 1.0 / ((st_tr * ms_per_step + st_va * val_ms) * 1e-3),
+            "epochs_per_sec": 1e3 / epoch_ms if epoch_ms else 1.0 / ((st_tr * ms_per_step + st_va * val_ms) * 1e-3),
+            "epochs_per_sec_note": (f"measured: 3 whole epochs ({st_tr} train + {st_va} validation steps each) through the "
+                                    "C-side epoch loop" if epoch_ms else "composed from ms_per_step and val_ms_per_step"),
+            "epoch_ms": epoch_ms,
             "val_ms_per_step": val_ms,
             "wide_hbm_frac_step": wide_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "enc_fwd_fused_into_enc_bwd": bool(fused_fwd),
