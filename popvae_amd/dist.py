@@ -94,10 +94,10 @@ class ShardedEngine:
             self._can_fuse = "next_rows" in inspect.signature(self.eng.stage_c).parameters
         except (TypeError, ValueError):
             self._can_fuse = False
-        # host-driven exchanges: with its own communicator the engine keeps its own (non-blocking) stream and torch is not
-        # involved in a step at all.  Otherwise the exchanges never touch torch's legacy default stream (its implicit synchronisation with every blocking stream
-        # of the process is what the dead-lock described in _allreduce hinged on): they run on a dedicated non-blocking torch
-        # stream, which is also the engine's stream in the stream-ordered variant.
+        # With its own communicator the engine keeps its own (non-blocking) stream and torch is not involved in a step at
+        # all.  Otherwise the exchanges run on a dedicated non-blocking torch stream (which is also the engine's stream in
+        # the stream-ordered variant) and never touch torch's legacy default stream, whose implicit synchronisation with
+        # every blocking stream of the process the dead-lock described in _allreduce hinged on.
         self._xs = None
         if not self.native and hasattr(self.eng, "set_stream") and torch.cuda.is_available():
             self._xs = torch.cuda.Stream(device=device_id)
@@ -118,13 +118,12 @@ class ShardedEngine:
         # half-built communicator state behind (later collectives of the process were seen to hang), so the ranks compare
         # device identities first and do not try
         import socket
-        dev = self.device_id
         try:
-            uid = str(self._torch.cuda.get_device_properties(self._torch.cuda.current_device() if dev is None else dev).uuid)
-        except Exception:
+            uid = str(self._torch.cuda.get_device_properties(self.device_id).uuid)
+        except Exception:  # older torch: no uuid; the visibility masks + ordinal still tell devices apart
             uid = None
         ident = (socket.gethostname(), uid, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"),
-                 self._torch.cuda.current_device() if dev is None else dev)
+                 self.device_id)
         idents = [None] * self.world
         dist.all_gather_object(idents, ident, group=self.pg)
         if len(set(idents)) < self.world:
