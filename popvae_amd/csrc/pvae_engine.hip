@@ -91,7 +91,7 @@ struct pvae_engine {
     int64_t enc_out_cap = 0;   // in batches
     // scratch
     float *encpart = nullptr, *dgpart = nullptr, *losspart = nullptr;
-    int enc_wgs = 0, dec_wgs = 0, encb_wgs = 0;
+    int enc_wgs = 0, dec_wgs = 0, encb_wgs = 0, dec_eval_wgs = 0;
     int64_t tile_floats = 0;
     int ts4 = 0;
     // fused narrow stack (width <= 128): op tables in device memory
@@ -257,6 +257,8 @@ void flush_timing(pvae_engine* e) {
 // ---- dynamic-LDS sizes ----
 size_t lds_dense_fwd(int K) { return (size_t)(32 * (K + 1) + 4096) * 4; }
 size_t lds_dense_bwd(int N) { return (size_t)(2 * 32 * (N + 1) + 4096) * 4; }
+// evaluation launches of pvk_dec use no per-wave staging tiles and no dg reduction: the g tile alone (more blocks per CU)
+size_t lds_dec_eval(int NWB) { return (size_t)(32 * (NWB * 32 + 1) + 64) * 4; }
 size_t lds_dec(int NWB) { return (size_t)(32 * (NWB * 32 + 1) + 4 * 3 * 32 * 33) * 4; }
 size_t lds_enc_bwd(int Wp) { return (size_t)32 * Wp * 4; }
 size_t lds_enc_bwd_fused(int NWB, int Wp) { return std::max<size_t>((size_t)32 * Wp * 4, (size_t)4 * NWB * 1024 * 4); }
@@ -565,7 +567,13 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
 #undef PV_K3
         } else {
 #define PV_K3(TR, MD) pvk_dec<N_, TR, MD>
-            PV_DISPATCH_NWB(e, PV_DEC_MODES(PV_K3, 256, lds_dec(N_)));
+            if (mode == 1) {  // read-only pass: small LDS footprint, its own (larger) grid
+                PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 0, PV_MODE_TRAIN>), dim3(e->dec_eval_wgs), dim3(256), lds_dec_eval(N_),
+                                                      e->stream, aV, amV, avV, aV2, amV2, avV2, acb, amC, avC, gD, e->Xt, e->nblk,
+                                                      (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4, agV, agC));
+            } else {
+                PV_DISPATCH_NWB(e, PV_DEC_MODES(PV_K3, 256, lds_dec(N_)));
+            }
 #undef PV_K3
         }
 #undef PV_DEC_MODES
@@ -574,8 +582,8 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
         if ((rc = launch_check(e, "dec"))) return rc;
         const int n_dg = mode == 1 ? 0 : 32 * e->Wp;
         // eval: only the recon sums are produced (they live behind the dg block of the exchange buffer)
-        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(n_dg)), dim3(256), 0, e->stream, e->dgpart, e->dec_wgs, n_dg, 1.0f,
-                           e->xch1, e->losspart, e->xch1 + 32 * e->Wp);
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(n_dg)), dim3(256), 0, e->stream, e->dgpart,
+                           mode == 1 ? e->dec_eval_wgs : e->dec_wgs, n_dg, 1.0f, e->xch1, e->losspart, e->xch1 + 32 * e->Wp);
         if ((rc = launch_check(e, "dec_reduce"))) return rc;
     }
     return 0;
@@ -1072,15 +1080,23 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
         if (e->ngrp == 1) e->dec_wgs = (int)((balance(e->nblk, (int64_t)cus * o_dec * 4) + 3) / 4);
         else e->dec_wgs = (int)balance((e->nblk + 8 / e->ngrp - 1) / (8 / e->ngrp), (int64_t)cus * o_dec);  // block groups per workgroup
         e->dec_wgs = clampi(envi("PVAE_DEC_WGS", e->dec_wgs), 1, (e->nblk + 3) / 4);
+        e->dec_eval_wgs = e->dec_wgs;
+        if (e->ngrp == 1) {
+            int o_eval = 2;
+            PV_DISPATCH_NWB(e, HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_eval, (pvk_dec<N_, 0, PV_MODE_TRAIN>), 256, lds_dec_eval(N_))));
+            // 4 blocks per CU measured best (C4: eval step 0.320 ms at 2, 0.279 at 4, 0.284 at 8; tools/gpu_eval_sweep.sh)
+            o_eval = envi("PVAE_DECE_OCC", std::min(std::max(o_eval, 1), 4));
+            e->dec_eval_wgs = (int)((balance(e->nblk, (int64_t)cus * o_eval * 4) + 3) / 4);
+        }
         e->encb_wgs = clampi(envi("PVAE_ENCB_WGS", e->encb_wgs) / e->ngrp, 1, (e->nblk + 3) / 4) * e->ngrp;
         if (getenv("PVAE_VERBOSE"))
-            fprintf(stderr, "[pvae] CUs %d; blocks/CU enc_fwd %d dec %d enc_bwd %d; grids %d %d %d\n", cus, o_enc, o_dec, o_encb,
-                    e->enc_wgs, e->dec_wgs, e->encb_wgs);
+            fprintf(stderr, "[pvae] CUs %d; blocks/CU enc_fwd %d dec %d enc_bwd %d; grids %d %d %d, dec eval %d\n", cus, o_enc, o_dec, o_encb,
+                    e->enc_wgs, e->dec_wgs, e->encb_wgs, e->dec_eval_wgs);
     }
     CK(allocf(e, &e->encpart, (int64_t)std::max(e->enc_wgs, e->encb_wgs) * e->NWB * 1024));
     e->fuse_fwd = !getenv("PVAE_NO_FUSE_FWD");
     CK(allocf(e, &e->dgpart, (int64_t)e->dec_wgs * 32 * e->Wp));
-    CK(allocf(e, &e->losspart, (int64_t)e->dec_wgs));
+    CK(allocf(e, &e->losspart, (int64_t)std::max(e->dec_wgs, e->dec_eval_wgs)));
 
     HK(hipMalloc(&e->st, sizeof(PvStep)));
     PvStep st0{};

@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
     lossacc += __shfl_xor(lossacc, 8);
     lossacc += __shfl_xor(lossacc, 16);
     lossacc += __shfl_xor(lossacc, 32);
-    float* lred = red + 4 * NWB * 1024;
+    float* lred = TRAIN ? red + 4 * NWB * 1024 : red;  // evaluation launches bring only the g tile's LDS (lds_dec_eval)
     if (lane == 0) lred[wave] = lossacc;
     if (TRAIN) {
 #pragma unroll
