@@ -262,8 +262,10 @@ size_t lds_dec_eval(int NWB) { return (size_t)(32 * (NWB * 32 + 1) + 64) * 4; }
 size_t lds_dec(int NWB) { return (size_t)(32 * (NWB * 32 + 1) + 4 * 3 * 32 * 33) * 4; }
 size_t lds_enc_bwd(int Wp) { return (size_t)32 * Wp * 4; }
 size_t lds_enc_bwd_fused(int NWB, int Wp) { return std::max<size_t>((size_t)32 * Wp * 4, (size_t)4 * NWB * 1024 * 4); }
+constexpr int dec_grp_waves(int ngrp) { return ngrp == 2 ? 4 : 8; }  // waves per workgroup of pvk_dec_grp
 size_t lds_dec_grp(int ngrp) {
-    return std::max<size_t>((size_t)32 * (ngrp * 128 + 1) + 8 * 2 * 32 * 33, (size_t)8 * 4 * 1024 + 8) * 4;
+    const size_t nw = dec_grp_waves(ngrp);
+    return std::max<size_t>((size_t)32 * (ngrp * 128 + 1) + nw * 2 * 32 * 33, nw * 4 * 1024 + nw) * 4;
 }
 size_t lds_enc_fwd(int NWB) { return (size_t)4 * NWB * 1024 * 4; }
 
@@ -298,10 +300,10 @@ int setup_kernel_attrs(pvae_engine* e) {
     }
 #undef PV_ATTR
 #define PV_ATTR_G(G)                                                                  \
-    HIPCHK(allow_lds(pvk_dec_grp<G, 1, PV_MODE_TRAIN>, lds_dec_grp(G)));              \
-    HIPCHK(allow_lds(pvk_dec_grp<G, 1, PV_MODE_GRAD>, lds_dec_grp(G)));               \
-    HIPCHK(allow_lds(pvk_dec_grp<G, 1, PV_MODE_TRAIN_ACC>, lds_dec_grp(G)));          \
-    HIPCHK(allow_lds(pvk_dec_grp<G, 0, PV_MODE_TRAIN>, lds_dec_grp(G)));
+    HIPCHK(allow_lds((pvk_dec_grp<G, 1, PV_MODE_TRAIN, dec_grp_waves(G)>), lds_dec_grp(G)));     \
+    HIPCHK(allow_lds((pvk_dec_grp<G, 1, PV_MODE_GRAD, dec_grp_waves(G)>), lds_dec_grp(G)));      \
+    HIPCHK(allow_lds((pvk_dec_grp<G, 1, PV_MODE_TRAIN_ACC, dec_grp_waves(G)>), lds_dec_grp(G))); \
+    HIPCHK(allow_lds((pvk_dec_grp<G, 0, PV_MODE_TRAIN, dec_grp_waves(G)>), lds_dec_grp(G)));
     if (e->ngrp == 2) { PV_ATTR_G(2) }
     if (e->ngrp == 4) { PV_ATTR_G(4) }
 #undef PV_ATTR_G
@@ -558,12 +560,12 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
         else PV_DEC_LAUNCH((K3(0, PV_MODE_TRAIN)), THREADS, LDS);                          \
     } while (0)
         if (e->ngrp == 2) {
-#define PV_K3(TR, MD) pvk_dec_grp<2, TR, MD>
-            PV_DEC_MODES(PV_K3, 512, lds_dec_grp(2));
+#define PV_K3(TR, MD) pvk_dec_grp<2, TR, MD, dec_grp_waves(2)>
+            PV_DEC_MODES(PV_K3, 64 * dec_grp_waves(2), lds_dec_grp(2));
 #undef PV_K3
         } else if (e->ngrp == 4) {
-#define PV_K3(TR, MD) pvk_dec_grp<4, TR, MD>
-            PV_DEC_MODES(PV_K3, 512, lds_dec_grp(4));
+#define PV_K3(TR, MD) pvk_dec_grp<4, TR, MD, dec_grp_waves(4)>
+            PV_DEC_MODES(PV_K3, 64 * dec_grp_waves(4), lds_dec_grp(4));
 #undef PV_K3
         } else {
 #define PV_K3(TR, MD) pvk_dec<N_, TR, MD>
@@ -1048,9 +1050,9 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
             if (e->ngrp == 1)
                 HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, pvk_dec<N_, 1, PV_MODE_TRAIN>, 256, lds_dec(N_)));
             else if (e->ngrp == 2)
-                HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, pvk_dec_grp<2, 1, PV_MODE_TRAIN>, 512, lds_dec_grp(2)));
+                HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, (pvk_dec_grp<2, 1, PV_MODE_TRAIN, dec_grp_waves(2)>), 64 * dec_grp_waves(2), lds_dec_grp(2)));
             else
-                HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, pvk_dec_grp<4, 1, PV_MODE_TRAIN>, 512, lds_dec_grp(4)));
+                HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, (pvk_dec_grp<4, 1, PV_MODE_TRAIN, dec_grp_waves(4)>), 64 * dec_grp_waves(4), lds_dec_grp(4)));
             if (!getenv("PVAE_NO_FUSE_FWD"))
                 HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_encb, (pvk_enc_bwd<N_, PV_MODE_TRAIN, 1>), 256, lds_enc_bwd_fused(N_, e->Wp)));
             else
@@ -1078,7 +1080,10 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
         e->enc_wgs = enc_grid(o_enc);
         e->encb_wgs = enc_grid(o_encb);
         if (e->ngrp == 1) e->dec_wgs = (int)((balance(e->nblk, (int64_t)cus * o_dec * 4) + 3) / 4);
-        else e->dec_wgs = (int)balance((e->nblk + 8 / e->ngrp - 1) / (8 / e->ngrp), (int64_t)cus * o_dec);  // block groups per workgroup
+        else {  // a workgroup takes dec_grp_waves / ngrp SNP blocks per iteration
+            const int bpi = dec_grp_waves(e->ngrp) / e->ngrp;
+            e->dec_wgs = (int)balance((e->nblk + bpi - 1) / bpi, (int64_t)cus * o_dec);
+        }
         e->dec_wgs = clampi(envi("PVAE_DEC_WGS", e->dec_wgs), 1, (e->nblk + 3) / 4);
         e->dec_eval_wgs = e->dec_wgs;
         if (e->ngrp == 1) {

@@ -662,14 +662,15 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
 
 // ---------------------------------------------------------------------------------------------
 // Wide decoder for widths above 128 (NGRP = Wp / 128 groups of 128 units, NGRP in {2, 4}).
-// Workgroup = 8 waves; wave = (block bsub = wave / NGRP, group grp = wave % NGRP), i.e. 8 / NGRP SNP blocks
-// per iteration.  Each wave forms the partial logits of its group; the partials meet in LDS (the wave's own
+// Workgroup = NW waves; wave = (block bsub = wave / NGRP, group grp = wave % NGRP), i.e. NW / NGRP SNP blocks
+// per iteration.  NW = 8 at width 512 (one workgroup per CU); NW = 4 at width 256, where two workgroups fit a CU's LDS and,
+// not sharing barriers, overlap each other's loads and compute.  Each wave forms the partial logits of its group; the partials meet in LDS (the wave's own
 // V^T staging area doubles as the mailbox) and every wave of a block sums them in group order, so all of
 // them hold bit-identical logits.  From there on each wave treats its group as pvk_dec does: dg partial,
 // dV + Adam on its own 32x128 subtile, which it still holds in registers -- no weight byte is read twice.
 // ---------------------------------------------------------------------------------------------
-template <int NGRP, int TRAIN, int MODE>
-__global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, const float* __restrict__ mV,
+template <int NGRP, int TRAIN, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __restrict__ V, const float* __restrict__ mV,
                                                    const float* __restrict__ vV, float* __restrict__ V2,
                                                    float* __restrict__ mV2, float* __restrict__ vV2,
                                                    float* __restrict__ cb, float* __restrict__ mC, float* __restrict__ vC,
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
     constexpr int NWB = 4;
     constexpr int WP = NGRP * 128;
     constexpr int LDG = WP + 1;
-    constexpr int BPI = 8 / NGRP;  // SNP blocks per workgroup iteration
+    constexpr int BPI = NW / NGRP;  // SNP blocks per workgroup iteration (NW waves per workgroup)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* g_s = smem;  // [32][LDG]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
@@ -693,7 +694,7 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
     const float inv_b = st->inv_b, alpha = st->alpha;
     const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
 
-    for (int i = tid; i < 32 * WP; i += 512) g_s[(i / WP) * LDG + (i % WP)] = g[i];
+    for (int i = tid; i < 32 * WP; i += NW * 64) g_s[(i / WP) * LDG + (i % WP)] = g[i];
     __syncthreads();
     const float* gg = g_s + grp * 128;  // this wave's 128 units
 
@@ -848,14 +849,14 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
     }
     // ---- per-workgroup reductions (fixed order) ----
     __syncthreads();
-    float* red = smem;  // [8 waves][NWB*16][64], then [8] loss
+    float* red = smem;  // [NW waves][NWB*16][64], then [NW] loss
     lossacc += __shfl_xor(lossacc, 1);
     lossacc += __shfl_xor(lossacc, 2);
     lossacc += __shfl_xor(lossacc, 4);
     lossacc += __shfl_xor(lossacc, 8);
     lossacc += __shfl_xor(lossacc, 16);
     lossacc += __shfl_xor(lossacc, 32);
-    float* lred = red + 8 * NWB * 1024;
+    float* lred = red + NW * NWB * 1024;
     if (lane == 0) lred[wave] = lossacc;
     if (TRAIN) {
 #pragma unroll
@@ -866,11 +867,11 @@ __global__ __launch_bounds__(512) void pvk_dec_grp(const float* __restrict__ V, 
     __syncthreads();
     if (tid == 0) {
         float sacc = 0.f;
-        for (int w2 = 0; w2 < 8; ++w2) sacc += lred[w2];
+        for (int w2 = 0; w2 < NW; ++w2) sacc += lred[w2];
         losspart[blockIdx.x] = sacc;
     }
     if (TRAIN) {
-        for (int e = tid; e < NGRP * NWB * 1024; e += 512) {
+        for (int e = tid; e < NGRP * NWB * 1024; e += NW * 64) {
             const int gq = e / (NWB * 1024), f = e % (NWB * 1024);
             float sum = red[(0 * NGRP + gq) * (NWB * 1024) + f];
 #pragma unroll
