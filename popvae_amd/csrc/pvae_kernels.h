@@ -669,6 +669,22 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
 // them hold bit-identical logits.  From there on each wave treats its group as pvk_dec does: dg partial,
 // dV + Adam on its own 32x128 subtile, which it still holds in registers -- no weight byte is read twice.
 // ---------------------------------------------------------------------------------------------
+// Sync point among the waves of ONE SNP block inside pvk_dec_grp (they share an LDS counter that only grows): arrive, then
+// wait until `target` arrivals.  All waves of a workgroup are resident, so the wait always ends; the spin is bounded all the
+// same (returns false when it gives up -- the caller then poisons its loss, loudly wrong instead of hung).
+__device__ __forceinline__ bool pv_block_sync(int* cnt, int target, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's LDS writes are done before it is counted
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    bool ok = false;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok;
+}
+
 template <int NGRP, int TRAIN, int MODE, int NW>
 __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __restrict__ V, const float* __restrict__ mV,
                                                    const float* __restrict__ vV, float* __restrict__ V2,
@@ -694,6 +710,10 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
     const float inv_b = st->inv_b, alpha = st->alpha;
     const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
 
+    // per SNP block of the workgroup: [0] partial logits posted, [1] partial logits read (both only ever grow)
+    __shared__ int blk_sync[BPI][2];
+    if (tid < 2 * BPI) blk_sync[tid >> 1][tid & 1] = 0;
+    bool sync_ok = true;
     for (int i = tid; i < 32 * WP; i += NW * 64) g_s[(i / WP) * LDG + (i % WP)] = g[i];
     __syncthreads();
     const float* gg = g_s + grp * 128;  // this wave's 128 units
@@ -707,11 +727,13 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
             for (int r = 0; r < 16; ++r) dg[w][r] = 0.f;
     }
 
+    int nsync = 0;
     for (int it = 0; it < per; ++it) {
         asm volatile("" ::: "memory");
         const int bg = it * (int)gridDim.x + blockIdx.x;  // round-robin over workgroups
         const int blk = bg * BPI + bsub;
-        const bool valid = bg < bgroups && blk < nblk;  // wave-uniform; invalid waves only keep the barriers
+        const bool valid = bg < bgroups && blk < nblk;  // the same for all waves of a block: they skip the iteration together
+        if (!valid) continue;
         const int64_t tbase = ((int64_t)blk * NGRP + grp) * ts;            // interleaved W|m|v tiles
         const int64_t gbase = ((int64_t)blk * NGRP + grp) * (NWB * 256);  // plain tiles (gradient dump)
         const f32x4* tV = reinterpret_cast<const f32x4*>(V) + tbase;
@@ -719,23 +741,24 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
         f32x16 a;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = 0.f;
-        if (valid) {
 #pragma unroll
-            for (int w = 0; w < NWB; ++w)
+        for (int w = 0; w < NWB; ++w)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) vv[w][q] = __builtin_nontemporal_load(tV + (w * 4 + q) * 64 + lane);
-            // (1) partial logits over this group's units
+            for (int q = 0; q < 4; ++q) vv[w][q] = __builtin_nontemporal_load(tV + (w * 4 + q) * 64 + lane);
+        // (1) partial logits over this group's units
 #pragma unroll
-            for (int w = 0; w < NWB; ++w)
+        for (int w = 0; w < NWB; ++w)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float ga = gg[c * LDG + w * 32 + PV_ROW(r, h)];
-                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, vv[w][r >> 2][r & 3], a, 0, 0, 0);
-                }
-        }
+            for (int r = 0; r < 16; ++r) {
+                const float ga = gg[c * LDG + w * 32 + PV_ROW(r, h)];
+                a = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, vv[w][r >> 2][r & 3], a, 0, 0, 0);
+            }
 #pragma unroll
         for (int r = 0; r < 16; ++r) vt[r * 64 + lane] = a[r];
-        __syncthreads();
+        // the NGRP waves of this SNP block meet here; the other blocks of the workgroup run on (a workgroup barrier at this
+        // point kept all waves of a CU in the same phase: loads and compute did not overlap)
+        ++nsync;
+        sync_ok &= pv_block_sync(&blk_sync[bsub][0], NGRP * nsync, lane);
         {
             const float* mb = smem + 32 * LDG + (bsub * NGRP) * (2 * 32 * 33);
 #pragma unroll
@@ -746,8 +769,8 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
                 a[r] = sum;
             }
         }
-        __syncthreads();
-        if (!valid) continue;
+        // mailboxes double as the V^T staging tiles of product (3): nobody overwrites one before all have read it
+        sync_ok &= pv_block_sync(&blk_sync[bsub][1], NGRP * nsync, lane);
         const int l = blk * 32 + c;
         const bool lvalid = l < L;
         const float bias = cb[l];
@@ -857,6 +880,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
     lossacc += __shfl_xor(lossacc, 16);
     lossacc += __shfl_xor(lossacc, 32);
     float* lred = red + NW * NWB * 1024;
+    if (!sync_ok) lossacc = __builtin_nanf("");  // a sync point gave up: make the step loudly wrong
     if (lane == 0) lred[wave] = lossacc;
     if (TRAIN) {
 #pragma unroll
