@@ -703,21 +703,17 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
             pp ^= 1;
         }
         // weight / bias gradients + Adam of all narrow layers: one launch, one wave per 32x32 block
-        const dim3 agrid((e->Wp / 32) * (e->Wp / 32), e->n_bwd_ops);
-        const dim3 bgrid((e->Wp + 63) / 64);
-        // first (wide) layer's bias rides on the dpre1 kernel
+        // one launch: rows 0 .. n_bwd_ops-1 of the grid are the Adam units, the last row the first (wide) layer's dpre / bias
+        const dim3 agrid((e->Wp / 32) * (e->Wp / 32), e->n_bwd_ops + 1);
         if (km == PV_MODE_GRAD) {
-            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_GRAD>, agrid, dim3(64), 0, e->stream, table, e->st, e->adam);
-            hipLaunchKernelGGL(pvk_bias_bwd<PV_MODE_GRAD>, bgrid, dim3(64), 0, e->stream, e->h[0], dY, e->Wp, (int)PV_ACT_ELU, e->dpre1,
-                               e->b1.w, e->b1.g, (float*)nullptr, e->st, e->adam, (const float*)nullptr);
+            hipLaunchKernelGGL(pvk_narrow_adam_bias<PV_MODE_GRAD>, agrid, dim3(64), 0, e->stream, table, e->st, e->adam, e->h[0], dY,
+                               e->Wp, (int)PV_ACT_ELU, e->dpre1, e->b1.w, e->b1.g, (float*)nullptr, (const float*)nullptr);
         } else if (km == PV_MODE_TRAIN_ACC) {
-            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN_ACC>, agrid, dim3(64), 0, e->stream, table, e->st, e->adam);
-            hipLaunchKernelGGL(pvk_bias_bwd<PV_MODE_TRAIN_ACC>, bgrid, dim3(64), 0, e->stream, e->h[0], dY, e->Wp, (int)PV_ACT_ELU,
-                               e->dpre1, e->b1.w, e->b1.m, e->b1.v, e->st, e->adam, (const float*)e->b1.g);
+            hipLaunchKernelGGL(pvk_narrow_adam_bias<PV_MODE_TRAIN_ACC>, agrid, dim3(64), 0, e->stream, table, e->st, e->adam, e->h[0], dY,
+                               e->Wp, (int)PV_ACT_ELU, e->dpre1, e->b1.w, e->b1.m, e->b1.v, (const float*)e->b1.g);
         } else {
-            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN>, agrid, dim3(64), 0, e->stream, table, e->st, e->adam);
-            hipLaunchKernelGGL(pvk_bias_bwd<PV_MODE_TRAIN>, bgrid, dim3(64), 0, e->stream, e->h[0], dY, e->Wp, (int)PV_ACT_ELU, e->dpre1,
-                               e->b1.w, e->b1.m, e->b1.v, e->st, e->adam, (const float*)nullptr);
+            hipLaunchKernelGGL(pvk_narrow_adam_bias<PV_MODE_TRAIN>, agrid, dim3(64), 0, e->stream, table, e->st, e->adam, e->h[0], dY,
+                               e->Wp, (int)PV_ACT_ELU, e->dpre1, e->b1.w, e->b1.m, e->b1.v, (const float*)nullptr);
         }
         if ((rc = launch_check(e, "narrow_adam/bias_bwd"))) return rc;
     }

@@ -397,10 +397,11 @@ __global__ __launch_bounds__(256) void pvk_dense_bwd(int K, const float* __restr
 // dpre = dY * act'(Y) (rows >= nrows zeroed) written out, plus bias gradient / Adam.  Used for the wide
 // first encoder layer whose weight gradient is formed by pvk_enc_bwd.
 template <int MODE>
-__global__ void pvk_bias_bwd(const float* __restrict__ Y, const float* __restrict__ dY, int N, int act,
-                             float* __restrict__ dpre, float* __restrict__ bias, float* __restrict__ mB,
-                             float* __restrict__ vB, const PvStep* st, PvAdam adam, const float* __restrict__ gB) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pv_bias_bwd_block(const float* __restrict__ Y, const float* __restrict__ dY, int N, int act,
+                                                  float* __restrict__ dpre, float* __restrict__ bias, float* __restrict__ mB,
+                                                  float* __restrict__ vB, const PvStep* st, const PvAdam& adam,
+                                                  const float* __restrict__ gB, int block) {
+    const int n = block * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const int nrows = st->nrows;
     float g = 0.f;
@@ -420,6 +421,13 @@ __global__ void pvk_bias_bwd(const float* __restrict__ Y, const float* __restric
         mB[n] = m;
         vB[n] = v;
     }
+}
+
+template <int MODE>
+__global__ void pvk_bias_bwd(const float* __restrict__ Y, const float* __restrict__ dY, int N, int act,
+                             float* __restrict__ dpre, float* __restrict__ bias, float* __restrict__ mB,
+                             float* __restrict__ vB, const PvStep* st, PvAdam adam, const float* __restrict__ gB) {
+    pv_bias_bwd_block<MODE>(Y, dY, N, act, dpre, bias, mB, vB, st, adam, gB, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------

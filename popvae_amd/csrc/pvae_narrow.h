@@ -639,6 +639,21 @@ __global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict_
     pvn_adam_unit<MODE>(ops, blockIdx.x, blockIdx.y, threadIdx.x, st, adam);
 }
 
+// Per-layer path (widths above 128): the narrow layers' dW + Adam units and, as one more row of the grid, the wide first
+// layer's dpre / bias update (pvk_bias_bwd) in ONE launch -- the two are independent and each was latency-bound.
+template <int MODE>
+__global__ __launch_bounds__(64) void pvk_narrow_adam_bias(const PvBwdOp* __restrict__ ops, const PvStep* __restrict__ st, PvAdam adam,
+                                                           const float* __restrict__ Y, const float* __restrict__ dY, int N, int act,
+                                                           float* __restrict__ dpre, float* __restrict__ bias,
+                                                           float* __restrict__ mB, float* __restrict__ vB,
+                                                           const float* __restrict__ gB) {
+    if (blockIdx.y + 1 == gridDim.y) {
+        pv_bias_bwd_block<MODE>(Y, dY, N, act, dpre, bias, mB, vB, st, adam, gB, blockIdx.x);  // blocks beyond N return
+        return;
+    }
+    pvn_adam_unit<MODE>(ops, blockIdx.x, blockIdx.y, threadIdx.x, st, adam);
+}
+
 // Rebuilds the operand-order copies from the Keras-layout kernels (after set_weights / init / restore).  grid = (16, n_ops),
 // 256 threads; destination-ordered, so the writes are coalesced.
 __global__ __launch_bounds__(256) void pvk_narrow_pack(const PvBwdOp* __restrict__ ops) {
