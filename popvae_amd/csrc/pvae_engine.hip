@@ -377,9 +377,10 @@ int shard_allreduce(pvae_engine* e, int which) {
 // ------------------------------------------------------------------------------------------------
 // forward / backward building blocks (all asynchronous on e->stream)
 // ------------------------------------------------------------------------------------------------
-int run_dense_fwd(pvae_engine* e, const Dense& d, const float* in, float* out) {
+int run_dense_fwd(pvae_engine* e, const Dense& d, const float* in, float* out, const float* in_bias = nullptr,
+                  float* in_act = nullptr) {
     hipLaunchKernelGGL(pvk_dense_fwd, dim3(d.nout / 32), dim3(256), lds_dense_fwd(d.kin), e->stream, in, d.kin, d.W.w,
-                       d.B.w, d.nout, d.act, out);
+                       d.B.w, d.nout, d.act, out, in_bias, in_act);
     return launch_check(e, "dense_fwd");
 }
 
@@ -504,12 +505,12 @@ int narrow_fused_fwd(pvae_engine* e, bool encoder_only, bool decoder_only = fals
 int narrow_encoder(pvae_engine* e) {
     int rc;
     if (e->fused_narrow) return narrow_fused_fwd(e, true);
-    hipLaunchKernelGGL(pvk_bias_act, dim3((32 * e->Wp + 255) / 256), dim3(256), 0, e->stream, e->P, e->b1.w, e->Wp,
-                       (int)PV_ACT_ELU, e->h[0]);
-    if ((rc = launch_check(e, "bias_act"))) return rc;
+    // h1 = elu(P + b1) is formed inside the first consumer's staging loop (workgroup 0 writes it out for the backward)
     for (int i = 0; i < e->D - 1; ++i)
-        if ((rc = run_dense_fwd(e, e->enc[i], e->h[i], e->h[i + 1]))) return rc;
-    if ((rc = run_dense_fwd(e, e->heads, e->h[e->D - 1], e->headout))) return rc;
+        if ((rc = i == 0 ? run_dense_fwd(e, e->enc[0], e->P, e->h[1], e->b1.w, e->h[0])
+                         : run_dense_fwd(e, e->enc[i], e->h[i], e->h[i + 1]))) return rc;
+    if ((rc = e->D == 1 ? run_dense_fwd(e, e->heads, e->P, e->headout, e->b1.w, e->h[0])
+                        : run_dense_fwd(e, e->heads, e->h[e->D - 1], e->headout))) return rc;
     hipLaunchKernelGGL(pvk_reparam, dim3(1), dim3(64), 0, e->stream, e->headout, e->Kh, e->K, e->eps, e->z, e->Kz, e->kl);
     return launch_check(e, "reparam");
 }
@@ -674,10 +675,11 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
         if (mode == 1) return 0;
         return enc_bwd_launch(e, km, fuse, next_off, next_n, ride ? table : nullptr);
     }
-    hipLaunchKernelGGL(pvk_loss_final, dim3(1), dim3(64), 0, e->stream, e->xch1 + 32 * e->Wp, e->kl, e->st, d_out3);
-    if ((rc = launch_check(e, "loss_final"))) return rc;
-    if (mode == 1) return 0;
-    {
+    if (mode == 1) {  // evaluation: the loss scalars are all there is left to do
+        hipLaunchKernelGGL(pvk_loss_final, dim3(1), dim3(64), 0, e->stream, e->xch1 + 32 * e->Wp, e->kl, e->st, d_out3);
+        return launch_check(e, "loss_final");
+    }
+    {   // (training: the loss scalars ride on the last launch of the chain, pvk_narrow_adam_bias)
         Timer t(e, C_NARROW_BWD);
         const int D = e->D;
         // the chain: per layer dpre (kept in dpre_bufs, in op-table order) and dIn; dY ping-pongs between xch1/dA/dB
@@ -704,16 +706,20 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
         }
         // weight / bias gradients + Adam of all narrow layers: one launch, one wave per 32x32 block
         // one launch: rows 0 .. n_bwd_ops-1 of the grid are the Adam units, the last row the first (wide) layer's dpre / bias
-        const dim3 agrid((e->Wp / 32) * (e->Wp / 32), e->n_bwd_ops + 1);
+        const int adam_x = (e->Wp / 32) * (e->Wp / 32);
+        const dim3 agrid(std::max(adam_x, (e->Wp + 63) / 64 + 1), e->n_bwd_ops + 1);
         if (km == PV_MODE_GRAD) {
             hipLaunchKernelGGL(pvk_narrow_adam_bias<PV_MODE_GRAD>, agrid, dim3(64), 0, e->stream, table, e->st, e->adam, e->h[0], dY,
-                               e->Wp, (int)PV_ACT_ELU, e->dpre1, e->b1.w, e->b1.g, (float*)nullptr, (const float*)nullptr);
+                               e->Wp, (int)PV_ACT_ELU, e->dpre1, e->b1.w, e->b1.g, (float*)nullptr, (const float*)nullptr, (const float*)(e->xch1 + 32 * e->Wp),
+                               (const float*)e->kl, d_out3, adam_x);
         } else if (km == PV_MODE_TRAIN_ACC) {
             hipLaunchKernelGGL(pvk_narrow_adam_bias<PV_MODE_TRAIN_ACC>, agrid, dim3(64), 0, e->stream, table, e->st, e->adam, e->h[0], dY,
-                               e->Wp, (int)PV_ACT_ELU, e->dpre1, e->b1.w, e->b1.m, e->b1.v, (const float*)e->b1.g);
+                               e->Wp, (int)PV_ACT_ELU, e->dpre1, e->b1.w, e->b1.m, e->b1.v, (const float*)e->b1.g, (const float*)(e->xch1 + 32 * e->Wp),
+                               (const float*)e->kl, d_out3, adam_x);
         } else {
             hipLaunchKernelGGL(pvk_narrow_adam_bias<PV_MODE_TRAIN>, agrid, dim3(64), 0, e->stream, table, e->st, e->adam, e->h[0], dY,
-                               e->Wp, (int)PV_ACT_ELU, e->dpre1, e->b1.w, e->b1.m, e->b1.v, (const float*)nullptr);
+                               e->Wp, (int)PV_ACT_ELU, e->dpre1, e->b1.w, e->b1.m, e->b1.v, (const float*)nullptr, (const float*)(e->xch1 + 32 * e->Wp),
+                               (const float*)e->kl, d_out3, adam_x);
         }
         if ((rc = launch_check(e, "narrow_adam/bias_bwd"))) return rc;
     }

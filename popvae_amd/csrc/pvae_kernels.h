@@ -260,7 +260,10 @@ __global__ void pvk_bias_act(const float* __restrict__ P, const float* __restric
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pvk_dense_fwd(const float* __restrict__ in, int K, const float* __restrict__ Wt,
                                                      const float* __restrict__ bias, int N, int act,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, const float* __restrict__ in_bias,
+                                                     float* __restrict__ in_act) {
+    // in_bias != NULL: the input is a pre-activation, elu(in + in_bias) is formed while staging and workgroup 0 also
+    // writes it to in_act (the first hidden layer: pvk_bias_act without a launch of its own)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* in_s = smem;                  // [32][K+1]
     float* red = smem + 32 * (K + 1);    // [4][16][64]
@@ -275,6 +278,12 @@ __global__ __launch_bounds__(256) void pvk_dense_fwd(const float* __restrict__ i
         for (int u = 0; u < 4; ++u) {
             const int i = 4 * (i0 + 256 * u);
             if (i < 32 * K) {
+                if (in_bias) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(in_bias + i % K);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[u][e] = pv_elu(v[u][e] + bq[e]);
+                    if (blockIdx.x == 0) *reinterpret_cast<f32x4*>(in_act + i) = v[u];
+                }
                 float* d = in_s + (i / K) * (K + 1) + (i % K);
                 d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
             }
@@ -964,8 +973,8 @@ __global__ __launch_bounds__(256) void pvk_dec_probs(const float* __restrict__ V
 }
 
 // loss = mean_b(recon + kl) over valid rows (popvae.py:423) -> out[0..2] = loss, mean recon, mean kl
-__global__ void pvk_loss_final(const float* __restrict__ recon, const float* __restrict__ kl, const PvStep* st,
-                               float* __restrict__ out) {
+__device__ __forceinline__ void pv_loss_final(const float* __restrict__ recon, const float* __restrict__ kl, const PvStep* st,
+                                              float* __restrict__ out) {
     if (threadIdx.x == 0) {
         const int n = st->nrows;
         float sr = recon[0], sk = 0.f;
@@ -974,6 +983,10 @@ __global__ void pvk_loss_final(const float* __restrict__ recon, const float* __r
         out[1] = sr * st->inv_b;
         out[2] = sk * st->inv_b;
     }
+}
+__global__ void pvk_loss_final(const float* __restrict__ recon, const float* __restrict__ kl, const PvStep* st,
+                               float* __restrict__ out) {
+    pv_loss_final(recon, kl, st, out);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -646,12 +646,16 @@ __global__ __launch_bounds__(64) void pvk_narrow_adam_bias(const PvBwdOp* __rest
                                                            const float* __restrict__ Y, const float* __restrict__ dY, int N, int act,
                                                            float* __restrict__ dpre, float* __restrict__ bias,
                                                            float* __restrict__ mB, float* __restrict__ vB,
-                                                           const float* __restrict__ gB) {
+                                                           const float* __restrict__ gB, const float* __restrict__ recon,
+                                                           const float* __restrict__ kl, float* __restrict__ out3, int adam_x) {
+    // adam_x = (Wp / 32)^2 units per layer; the grid is wider when the last row needs more blocks (Wp = 32)
     if (blockIdx.y + 1 == gridDim.y) {
-        pv_bias_bwd_block<MODE>(Y, dY, N, act, dpre, bias, mB, vB, st, adam, gB, blockIdx.x);  // blocks beyond N return
+        // the step's loss scalars (pvk_loss_final) take the first block behind the bias blocks
+        if (out3 && (int)blockIdx.x == (N + 63) / 64) pv_loss_final(recon, kl, st, out3);
+        else pv_bias_bwd_block<MODE>(Y, dY, N, act, dpre, bias, mB, vB, st, adam, gB, blockIdx.x);  // blocks beyond N return
         return;
     }
-    pvn_adam_unit<MODE>(ops, blockIdx.x, blockIdx.y, threadIdx.x, st, adam);
+    if ((int)blockIdx.x < adam_x) pvn_adam_unit<MODE>(ops, blockIdx.x, blockIdx.y, threadIdx.x, st, adam);
 }
 
 // Rebuilds the operand-order copies from the Keras-layout kernels (after set_weights / init / restore).  grid = (16, n_ops),
