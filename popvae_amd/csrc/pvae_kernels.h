@@ -269,52 +269,72 @@ __global__ __launch_bounds__(256) void pvk_dense_fwd(const float* __restrict__ i
     float* red = smem + 32 * (K + 1);    // [4][16][64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.x * 32;
-    // 16-byte loads, 4 in flight per thread (K is a multiple of 32, so a float4 never straddles a row)
-    for (int i0 = tid; i0 < 8 * K; i0 += 1024) {
-        f32x4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const f32x4*>(in)[min(i0 + 256 * u, 8 * K - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = 4 * (i0 + 256 * u);
-            if (i < 32 * K) {
-                if (in_bias) {
-                    const f32x4 bq = *reinterpret_cast<const f32x4*>(in_bias + i % K);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[u][e] = pv_elu(v[u][e] + bq[e]);
-                    if (blockIdx.x == 0) *reinterpret_cast<f32x4*>(in_act + i) = v[u];
-                }
-                float* d = in_s + (i / K) * (K + 1) + (i % K);
-                d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
-            }
-        }
-    }
-    __syncthreads();
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int kper = K / 4;  // multiple of 8
-    // 4 MFMA steps (8 k) per group, all operand loads of a group issued before its MFMAs; a load inside a
-    // rolled loop is waited for every iteration (one L2 round trip per MFMA)
-    auto run = [&](auto G) {
-        constexpr int S = decltype(G)::value;  // MFMA steps per group
-        for (int k = wave * kper; k < (wave + 1) * kper; k += 2 * S) {
-            float a[S], b[S];
+    const int kper = K / 4;  // this wave's share of the contraction, a multiple of 8
+    // one float4 of the input tile: (bias + ELU on the way in,) scattered into the padded LDS rows
+    auto put = [&](int i, f32x4 v) {
+        if (in_bias) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(in_bias + i % K);
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                a[s] = in_s[c * (K + 1) + k + 2 * s + h];
-                b[s] = Wt[(int64_t)(k + 2 * s + h) * N + n0 + c];
-            }
-#pragma unroll
-            for (int s = 0; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) v[e] = pv_elu(v[e] + bq[e]);
+            if (blockIdx.x == 0) *reinterpret_cast<f32x4*>(in_act + i) = v;
         }
+        float* d = in_s + (i / K) * (K + 1) + (i % K);
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
     };
-    // widths 512 / 256: the wave's whole k range in ONE group -- every weight load of the layer is in flight before the
-    // first MFMA, one L2 round trip per layer instead of one per 16 steps
-    if (kper == 128) run(std::integral_constant<int, 64>{});
-    else if (kper == 64) run(std::integral_constant<int, 32>{});
-    else if (kper % 32 == 0) run(std::integral_constant<int, 16>{});
-    else run(std::integral_constant<int, 4>{});
+    // Widths 512 / 256: ONE round trip per layer -- the wave's whole k range of weights (S loads) is requested first, then
+    // the whole input tile (NU float4 per thread), and only then anything is waited for.  (16 steps per group and 4 staging
+    // loads in flight, the first version, paid 4 + 4 dependent round trips: 11 us per layer against 6-7.)
+    auto whole = [&](auto Sc, auto NUc) {
+        constexpr int S = decltype(Sc)::value, NU = decltype(NUc)::value;
+        float b[S];
+        const int k = wave * kper;
+#pragma unroll
+        for (int s = 0; s < S; ++s) b[s] = Wt[(int64_t)(k + 2 * s + h) * N + n0 + c];
+        f32x4 v[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) v[u] = reinterpret_cast<const f32x4*>(in)[tid + 256 * u];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) put(4 * (tid + 256 * u), v[u]);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in_s[c * (K + 1) + k + 2 * s + h], b[s], acc, 0, 0, 0);
+    };
+    if (K == 512) {
+        whole(std::integral_constant<int, 64>{}, std::integral_constant<int, 16>{});
+    } else if (K == 256) {
+        whole(std::integral_constant<int, 32>{}, std::integral_constant<int, 8>{});
+    } else {
+        // 16-byte loads, 4 in flight per thread (K is a multiple of 32, so a float4 never straddles a row)
+        for (int i0 = tid; i0 < 8 * K; i0 += 1024) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const f32x4*>(in)[min(i0 + 256 * u, 8 * K - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (4 * (i0 + 256 * u) < 32 * K) put(4 * (i0 + 256 * u), v[u]);
+        }
+        __syncthreads();
+        // 4 MFMA steps (8 k) per group, all operand loads of a group issued before its MFMAs; a load inside a
+        // rolled loop is waited for every iteration (one L2 round trip per MFMA)
+        auto run = [&](auto G) {
+            constexpr int S = decltype(G)::value;  // MFMA steps per group
+            for (int k = wave * kper; k < (wave + 1) * kper; k += 2 * S) {
+                float a[S], b[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    a[s] = in_s[c * (K + 1) + k + 2 * s + h];
+                    b[s] = Wt[(int64_t)(k + 2 * s + h) * N + n0 + c];
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+            }
+        };
+        if (kper % 32 == 0) run(std::integral_constant<int, 16>{});
+        else run(std::integral_constant<int, 4>{});
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
@@ -346,33 +366,39 @@ __global__ __launch_bounds__(256) void pvk_dense_bwd(int K, const float* __restr
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int k0 = blockIdx.x * 32;
     const int nrows = st->nrows;
-    // 16-byte loads, 4 x 3 in flight per thread (N is a multiple of 32, so a float4 never straddles a row)
-    for (int i0 = tid; i0 < 8 * N; i0 += 1024) {
-        f32x4 yv[4], dv[4], wv[4];
+    // 16-byte loads, NU x 3 in flight per thread and round (N is a multiple of 32, so a float4 never straddles a row):
+    // 8 at widths 256 / 512 (one / two rounds), 4 otherwise
+    auto stage = [&](auto NUc) {
+        constexpr int NU = decltype(NUc)::value;
+        for (int i0 = tid; i0 < 8 * N; i0 += 256 * NU) {
+            f32x4 yv[NU], dv[NU], wv[NU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i4 = min(i0 + 256 * u, 8 * N - 1), i = 4 * i4;
-            const int b = i / N, n = i % N;
-            dv[u] = reinterpret_cast<const f32x4*>(dY)[i4];
-            if (act == PV_ACT_ELU) yv[u] = reinterpret_cast<const f32x4*>(Y)[i4];
-            wv[u] = *reinterpret_cast<const f32x4*>(Wt + (int64_t)(k0 + b) * N + n);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = 4 * (i0 + 256 * u);
-            if (i < 32 * N) {
+            for (int u = 0; u < NU; ++u) {
+                const int i4 = min(i0 + 256 * u, 8 * N - 1), i = 4 * i4;
                 const int b = i / N, n = i % N;
+                dv[u] = reinterpret_cast<const f32x4*>(dY)[i4];
+                if (act == PV_ACT_ELU) yv[u] = reinterpret_cast<const f32x4*>(Y)[i4];
+                wv[u] = *reinterpret_cast<const f32x4*>(Wt + (int64_t)(k0 + b) * N + n);
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float d = b < nrows ? dv[u][e] : 0.f;
-                    if (act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[u][e]);
-                    dp_s[b * ld + n + e] = d;
-                    w_s[b * ld + n + e] = wv[u][e];
-                    if (blockIdx.x == 0) dpre_out[i + e] = d;
+            for (int u = 0; u < NU; ++u) {
+                const int i = 4 * (i0 + 256 * u);
+                if (i < 32 * N) {
+                    const int b = i / N, n = i % N;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float d = b < nrows ? dv[u][e] : 0.f;
+                        if (act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[u][e]);
+                        dp_s[b * ld + n + e] = d;
+                        w_s[b * ld + n + e] = wv[u][e];
+                        if (blockIdx.x == 0) dpre_out[i + e] = d;
+                    }
                 }
             }
         }
-    }
+    };
+    if (N % 256 == 0) stage(std::integral_constant<int, 8>{});
+    else stage(std::integral_constant<int, 4>{});
     __syncthreads();
     f32x16 acc;
 #pragma unroll
