@@ -378,15 +378,18 @@ int shard_allreduce(pvae_engine* e, int which) {
 // forward / backward building blocks (all asynchronous on e->stream)
 // ------------------------------------------------------------------------------------------------
 int run_dense_fwd(pvae_engine* e, const Dense& d, const float* in, float* out, const float* in_bias = nullptr,
-                  float* in_act = nullptr) {
+                  float* in_act = nullptr, PvRepFwd rp = PvRepFwd{}) {
+    if (rp.z && d.nout != 32) return set_err(e, -6, "sampling tail on a layer of %d outputs", d.nout);
     hipLaunchKernelGGL(pvk_dense_fwd, dim3(d.nout / 32), dim3(256), lds_dense_fwd(d.kin), e->stream, in, d.kin, d.W.w,
-                       d.B.w, d.nout, d.act, out, in_bias, in_act);
+                       d.B.w, d.nout, d.act, out, in_bias, in_act, rp);
     return launch_check(e, "dense_fwd");
 }
 
-int run_dense_bwd(pvae_engine* e, Dense& d, const float* Y, const float* dY, float* dIn, float* dpre_out) {
+int run_dense_bwd(pvae_engine* e, Dense& d, const float* Y, const float* dY, float* dIn, float* dpre_out,
+                  PvRepBwd rp = PvRepBwd{}) {
+    if (rp.dheads && d.kin != 32) return set_err(e, -6, "sampling-gradient tail on a layer of %d inputs", d.kin);
     hipLaunchKernelGGL(pvk_dense_bwd, dim3(d.kin / 32), dim3(256), lds_dense_bwd(d.nout), e->stream, d.kin, d.W.w, d.nout,
-                       d.act, Y, dY, dIn, dpre_out, e->st);
+                       d.act, Y, dY, dIn, dpre_out, e->st, rp);
     return launch_check(e, "dense_bwd");
 }
 
@@ -509,6 +512,12 @@ int narrow_encoder(pvae_engine* e) {
     for (int i = 0; i < e->D - 1; ++i)
         if ((rc = i == 0 ? run_dense_fwd(e, e->enc[0], e->P, e->h[1], e->b1.w, e->h[0])
                          : run_dense_fwd(e, e->enc[i], e->h[i], e->h[i + 1]))) return rc;
+    // the heads layer is one workgroup (Kh = 32 outputs): the sampling layer + KL run in its tail
+    if (e->Kh == 32) {
+        const PvRepFwd rp{e->eps, e->z, e->kl, e->K, e->Kz};
+        return e->D == 1 ? run_dense_fwd(e, e->heads, e->P, e->headout, e->b1.w, e->h[0], rp)
+                         : run_dense_fwd(e, e->heads, e->h[e->D - 1], e->headout, nullptr, nullptr, rp);
+    }
     if ((rc = e->D == 1 ? run_dense_fwd(e, e->heads, e->P, e->headout, e->b1.w, e->h[0])
                         : run_dense_fwd(e, e->heads, e->h[e->D - 1], e->headout))) return rc;
     hipLaunchKernelGGL(pvk_reparam, dim3(1), dim3(64), 0, e->stream, e->headout, e->Kh, e->K, e->eps, e->z, e->Kz, e->kl);
@@ -692,10 +701,15 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
             dY = bufs[pp];
             pp ^= 1;
         }
-        if ((rc = run_dense_bwd(e, e->dec[0], e->g[0], dY, e->dz, e->dpre_bufs[li++]))) return rc;
-        hipLaunchKernelGGL(pvk_reparam_bwd, dim3(1), dim3(64), 0, e->stream, e->headout, e->Kh, e->K, e->eps, e->dz, e->Kz,
-                           e->dheads, e->st);
-        if ((rc = launch_check(e, "reparam_bwd"))) return rc;
+        if (e->Kz == 32) {  // one workgroup: dz -> d heads in the tail
+            const PvRepBwd rp{e->headout, e->eps, e->dheads, e->Kh, e->K};
+            if ((rc = run_dense_bwd(e, e->dec[0], e->g[0], dY, e->dz, e->dpre_bufs[li++], rp))) return rc;
+        } else {
+            if ((rc = run_dense_bwd(e, e->dec[0], e->g[0], dY, e->dz, e->dpre_bufs[li++]))) return rc;
+            hipLaunchKernelGGL(pvk_reparam_bwd, dim3(1), dim3(64), 0, e->stream, e->headout, e->Kh, e->K, e->eps, e->dz, e->Kz,
+                               e->dheads, e->st);
+            if ((rc = launch_check(e, "reparam_bwd"))) return rc;
+        }
         if ((rc = run_dense_bwd(e, e->heads, e->headout, e->dheads, bufs[pp], e->dpre_bufs[li++]))) return rc;
         dY = bufs[pp];
         pp ^= 1;

@@ -30,6 +30,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define PV_ROW(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))
+// index of element (row b, column n) of a 32 x 32 result in the [16][64] accumulator-ordered LDS tile: inverse of PV_ROW
+#define PV_TILE_IDX(b, n) (((((b) & 3) + 4 * ((b) >> 3)) << 6) + ((((b) >> 2) & 1) << 5) + (n))
+
+// Optional tails of the per-layer dense kernels (widths above 128), for the two layers that are a single workgroup:
+// the heads layer's forward also does the sampling layer + KL (pvk_reparam), the first decoder layer's backward also
+// turns dz into the heads' gradient (pvk_reparam_bwd).  z == NULL / dheads == NULL: no tail.
+struct PvRepFwd { const float* eps; float* z; float* kl; int K, ldz; };
+struct PvRepBwd { const float* heads; const float* eps; float* dheads; int ldh, K; };
 
 enum { PV_ACT_LINEAR = 0, PV_ACT_ELU = 1 };
 // TRAIN: Adam in the pass.  GRAD: gradient dump (PvStep.acc: store / add).  TRAIN_ACC: Adam on (this pass's gradient +
@@ -261,7 +269,7 @@ __global__ void pvk_bias_act(const float* __restrict__ P, const float* __restric
 __global__ __launch_bounds__(256) void pvk_dense_fwd(const float* __restrict__ in, int K, const float* __restrict__ Wt,
                                                      const float* __restrict__ bias, int N, int act,
                                                      float* __restrict__ out, const float* __restrict__ in_bias,
-                                                     float* __restrict__ in_act) {
+                                                     float* __restrict__ in_act, PvRepFwd rp) {
     // in_bias != NULL: the input is a pre-activation, elu(in + in_bias) is formed while staging and workgroup 0 also
     // writes it to in_act (the first hidden layer: pvk_bias_act without a launch of its own)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -343,7 +351,27 @@ __global__ __launch_bounds__(256) void pvk_dense_fwd(const float* __restrict__ i
         const int r = e >> 6, l = e & 63;
         const int b = PV_ROW(r, l >> 5), n = n0 + (l & 31);
         const float x = s + bias[n];
-        out[b * N + n] = act == PV_ACT_ELU ? pv_elu(x) : x;
+        const float y = act == PV_ACT_ELU ? pv_elu(x) : x;
+        out[b * N + n] = y;
+        if (rp.z) red[e] = y;  // slot e of the first quarter is read by this thread only
+    }
+    if (rp.z) {  // heads layer (N == 32, one workgroup): z = mu + exp(s) * eps and the KL term, as pvk_reparam
+        __syncthreads();
+        const int b = tid;
+        if (b < 32) {
+            float kacc = 0.f;
+            for (int k = 0; k < rp.ldz; ++k) {
+                float zz = 0.f;
+                if (k < rp.K) {
+                    const float mu = red[PV_TILE_IDX(b, k)], sv = red[PV_TILE_IDX(b, rp.K + k)];
+                    const float es = expf(sv);
+                    zz = mu + es * rp.eps[b * rp.K + k];  // NOTE exp(s), not exp(s/2): popvae.py:389
+                    kacc += 1.f + sv - mu * mu - es;
+                }
+                rp.z[b * rp.ldz + k] = zz;
+            }
+            rp.kl[b] = -0.5f * kacc;
+        }
     }
 }
 
@@ -357,7 +385,7 @@ __global__ __launch_bounds__(256) void pvk_dense_fwd(const float* __restrict__ i
 __global__ __launch_bounds__(256) void pvk_dense_bwd(int K, const float* __restrict__ Wt, int N, int act,
                                                      const float* __restrict__ Y, const float* __restrict__ dY,
                                                      float* __restrict__ dIn, float* __restrict__ dpre_out,
-                                                     const PvStep* st) {
+                                                     const PvStep* st, PvRepBwd rp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ld = N + 1;
     float* dp_s = smem;             // [32][N+1]
@@ -426,6 +454,24 @@ __global__ __launch_bounds__(256) void pvk_dense_bwd(int K, const float* __restr
         const float s = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
         const int r = e >> 6, l = e & 63;
         dIn[PV_ROW(r, l >> 5) * K + k0 + (l & 31)] = s;
+        if (rp.dheads) red[e] = s;  // slot e of the first quarter is read by this thread only
+    }
+    if (rp.dheads) {  // first decoder layer (K == 32, one workgroup): dz -> d heads, as pvk_reparam_bwd
+        __syncthreads();
+        const int b = tid;
+        if (b < 32) {
+            const bool valid = b < nrows;
+            const float ib = st->inv_b;
+            for (int k = 0; k < rp.ldh; ++k) rp.dheads[b * rp.ldh + k] = 0.f;
+            if (valid) {
+                for (int k = 0; k < rp.K; ++k) {
+                    const float mu = rp.heads[b * rp.ldh + k], sv = rp.heads[b * rp.ldh + rp.K + k];
+                    const float es = expf(sv), d = red[PV_TILE_IDX(b, k)];
+                    rp.dheads[b * rp.ldh + k] = d + mu * ib;
+                    rp.dheads[b * rp.ldh + rp.K + k] = d * rp.eps[b * rp.K + k] * es + 0.5f * (es - 1.f) * ib;
+                }
+            }
+        }
     }
 }
 
