@@ -46,6 +46,9 @@ CASES = [
     (40, 700, 256, 3, 2, 32),      # two groups of 128 units (grouped wide decoder, per-layer narrow kernels)
     (40, 1000, 512, 2, 2, 19),     # four groups, short batch (C3 / grid-search width)
     (40, 500, 200, 2, 3, 32),      # width 200 padded to 256
+    (40, 600, 128, 2, 16, 25),     # 16 latent dimensions (the engine's maximum: the two heads fill one 32-column tile)
+    (40, 400, 256, 1, 2, 32),      # depth 1 above width 128: the heads layer forms elu(P + b1) itself
+    (40, 400, 512, 3, 16, 32),     # 16 latent dimensions: heads exactly 32 columns (sampling layer in the heads layer's tail)
 ]
 
 
