@@ -1309,7 +1309,9 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
             for (int t = 0; t * 32 < nb; ++t) {
                 hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, 32 * e->K, e->cfg.seed, e->d_counter);
                 if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
-                const int tm = phase == 1 ? 1 : (t + 1) * 32 >= nb ? 4 : 2;
+                // a short last batch of at most 32 rows is ONE tile: a plain train step (TRAIN_ACC would add the gradient
+                // dump the previous batch's tiles left behind, or find none at all when n_train <= 32 < batch_size)
+                const int tm = phase == 1 ? 1 : nb <= 32 ? 0 : (t + 1) * 32 >= nb ? 4 : 2;
                 if ((rc = run_tile(e, base + s * B + 32 * t, std::min(32, nb - 32 * t), nb, t, tm, slot + 3 * t))) return rc;
             }
         }

@@ -50,6 +50,18 @@ def test_pack_helper_matches_front_end():
     ("C4-short-batch", 1_000_000, 128, 6, 13),   # 2253 % 32 = 13: the epoch's last batch at C4
     ("C3", 500_000, 512, 6, 32),
     ("C5", 200_000, 256, 5, 32),
+    # BASELINE config 5 is the whole grid widths {32, 256, 512} x depths {3, 5, 8} on 200 k SNPs (popvae.py:280-369)
+    ("C5-32x3", 200_000, 32, 3, 32),
+    ("C5-32x5", 200_000, 32, 5, 32),
+    ("C5-32x8", 200_000, 32, 8, 32),
+    ("C5-256x3", 200_000, 256, 3, 32),
+    ("C5-256x8", 200_000, 256, 8, 32),
+    ("C5-512x3", 200_000, 512, 3, 32),
+    ("C5-512x5", 200_000, 512, 5, 32),
+    ("C5-512x8", 200_000, 512, 8, 32),
+    # the reference's default --depth_range ends at 10 and 20 (popvae.py:66-74)
+    ("C2-depth20", 100_000, 128, 20, 32),
+    ("C5-256x10", 200_000, 256, 10, 19),
 ])
 def test_full_size_loss_and_gradients_vs_oracle(name, L, W, D, n):
     N, K = 40, 2

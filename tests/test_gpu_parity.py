@@ -49,6 +49,15 @@ CASES = [
     (40, 600, 128, 2, 16, 25),     # 16 latent dimensions (the engine's maximum: the two heads fill one 32-column tile)
     (40, 400, 256, 1, 2, 32),      # depth 1 above width 128: the heads layer forms elu(P + b1) itself
     (40, 400, 512, 3, 16, 32),     # 16 latent dimensions: heads exactly 32 columns (sampling layer in the heads layer's tail)
+    # the reference's default --depth_range is 3,6,10,20 (popvae.py:66-74, grid loop :280-369) and BASELINE config 5 has depth 8:
+    # both narrow paths (op-table chain at width <= 128, per-layer kernels above)
+    (40, 500, 128, 8, 2, 32),
+    (40, 500, 64, 10, 2, 32),
+    (40, 300, 128, 20, 2, 27),     # 42 ops in the chain's table (PVN_MAXOPS 64)
+    (40, 300, 32, 20, 2, 32),
+    (40, 400, 256, 8, 2, 32),
+    (40, 300, 512, 10, 2, 32),
+    (40, 300, 256, 20, 2, 9),
 ]
 
 
@@ -109,7 +118,8 @@ def test_weight_roundtrip_and_layouts():
     e.close()
 
 
-@pytest.mark.parametrize("L,W,D", [(1000, 128, 3), (3887, 128, 6), (900, 256, 3), (700, 512, 2)])
+@pytest.mark.parametrize("L,W,D", [(1000, 128, 3), (3887, 128, 6), (900, 256, 3), (700, 512, 2),
+                                   (600, 128, 20), (600, 128, 10), (500, 256, 20), (400, 512, 8)])
 def test_adam_training_steps_match_oracle(L, W, D):
     """Five fused-Adam train steps (incl. a short batch) vs oracle float64 Keras-Adam."""
     N, K = 64, 2
@@ -219,6 +229,38 @@ def test_large_batch_epoch_learns():
     lv, _, _ = e.eval_step(val)
     assert abs(lv - vloss) <= 0.02 * abs(vloss)
     e.close()
+
+
+@pytest.mark.parametrize("B,n_train", [(72, 170), (64, 161), (64, 20), (96, 32), (80, 80)])
+def test_large_batch_epoch_equals_stepwise(B, n_train):
+    """pvae_train_epoch with batch_size > 32 against a loop of pvae_train_step / pvae_eval_step calls on the same rows and
+    the same engine noise stream (one draw per 32-row tile on both paths): same per-batch losses, same weights and Adam
+    moments.  Batch shapes: 72/72/26 and 64/64/33 (short last batch of one tile / of a full tile + one row), 20 and 32
+    rows in all (n_train <= 32 < batch_size: the only batch is a single tile), 80 (no short batch).  The stepwise path is
+    the one test_large_batch_adam_steps_match_oracle pins against the oracle."""
+    N, L, W, D, K = 200, 900, 128, 3, 2
+    dc, w = _problem(N, L, W, D, K, seed=31)
+    g = np.random.default_rng(7)
+    perm = g.permutation(N)[:n_train].astype(np.int32)
+    val = np.arange(N - 45, N, dtype=np.int32)
+    res = []
+    for mode in ("epoch", "steps"):
+        e = _mk(dc, w, W, D, K, B=B, seed=5)
+        for _ in range(2):  # two epochs: the second starts with whatever gradient dump the first one left behind
+            if mode == "epoch":
+                loss, vloss = e.train_epoch(perm, val)
+            else:
+                tl = [e.train_step(perm[i:i + B])[0] for i in range(0, n_train, B)]
+                vl = [e.eval_step(val[i:i + B])[0] for i in range(0, len(val), B)]
+                loss, vloss = np.mean(tl), np.mean(vl)
+        res.append((loss, vloss, e.get_weights(), e.get_moments(0), e.get_moments(1)))
+        e.close()
+    (la, va, wa, ma, sa), (lb, vb, wb, mb, sb) = res
+    assert abs(la - lb) <= 1e-6 * abs(lb) and abs(va - vb) <= 1e-6 * abs(vb), (la, lb, va, vb)
+    for i, (a, b) in enumerate(zip(wa, wb)):
+        assert np.array_equal(a, b), ("w", i, np.abs(a - b).max())
+    for i, (a, b) in enumerate(zip(ma + sa, mb + sb)):
+        assert np.array_equal(a, b), ("m/v", i, np.abs(a - b).max())
 
 
 def test_encode_matches_oracle():
