@@ -77,6 +77,14 @@ int pvae_get_lr(pvae_engine* e, float* lr);
  * eps = injected N(0,1) [n][latent_dim] or NULL for the engine's own stream.
  * out3 = {loss, mean reconstruction, mean KL} or NULL (no host sync when NULL). */
 int pvae_train_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3);
+/* No counterpart in the reference: pvae_train_step for callers that cannot allocate (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  Same arguments, same result bit for bit; the wide kernels'
+ * split-K / split-N partial sums live in a file-scope device array of the library (32 MiB per GPU, held until the
+ * process ends) instead of hipMalloc'ed buffers, and the call performs no hipMalloc / hipHostMalloc / hipFree / event
+ * creation.  Limits: 1 <= n <= 32 rows (one device pass), world == 1, event timing off, and the model's partial-sum
+ * buffers must fit the array (every width up to 512 on a 256-CU device does; otherwise error -8).  All calls on one GPU
+ * share that GPU's array: calls that overlap on one GPU (two engines on two host threads) race. */
+int pvae_train_step_noalloc(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3);
 /* one test_step (validation; forward + loss, no update) */
 int pvae_eval_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3);
 /* same forward/backward as pvae_train_step but gradients are stored instead of applied (test hook for

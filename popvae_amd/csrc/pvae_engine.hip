@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -27,7 +28,14 @@
 #include "pvae_narrow.h"
 #include "pvae_pca.h"
 
-#define PV_VERSION "popvae_amd 0.1.0 (gfx950)"
+#define PV_VERSION "popvae_amd 0.2.0 (gfx950)"
+
+// pvae_train_step_noalloc: the split-K / split-N partial sums of the wide kernels (encpart, dgpart, losspart) live in this
+// file-scope device array instead of hipMalloc'ed buffers.  32 MiB per GPU the library runs on, held until the process
+// ends; every call on a GPU shares that GPU's copy (calls that overlap on one GPU race).  In host code the array's name
+// is only a handle for hipGetSymbolAddress: kernels get the per-device address kept in g_scratch_addr.
+#define PV_SCRATCH_BYTES (32u << 20)
+static __device__ __align__(256) float pv_scratch[PV_SCRATCH_BYTES / sizeof(float)];
 
 namespace {
 
@@ -91,6 +99,8 @@ struct pvae_engine {
     int64_t enc_out_cap = 0;   // in batches
     // scratch
     float *encpart = nullptr, *dgpart = nullptr, *losspart = nullptr;
+    float* scratch = nullptr;      // this device's copy of pv_scratch (hipGetSymbolAddress at pvae_create)
+    float* h_out3 = nullptr;       // pinned staging of {loss, recon, kl}
     int enc_wgs = 0, dec_wgs = 0, encb_wgs = 0, dec_eval_wgs = 0;
     int64_t tile_floats = 0;
     int ts4 = 0;
@@ -151,6 +161,24 @@ int set_err(pvae_engine* e, int code, const char* fmt, ...) {
     } while (0)
 
 int pad32(int x) { return (x + 31) / 32 * 32; }
+
+// address of pv_scratch on device `dev` (each GPU holds its own copy at its own address): looked up once per device,
+// with that device current
+std::mutex g_scratch_mu;
+float* g_scratch_addr[64] = {nullptr};
+int scratch_address(pvae_engine* e, int dev, float** out) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (dev < 0 || dev >= 64) return set_err(e, -2, "device ordinal %d beyond the scratch table", dev);
+    if (!g_scratch_addr[dev]) {
+        HIPCHK(hipSetDevice(dev));
+        void* p = nullptr;
+        HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(pv_scratch)));
+        if (!p) return set_err(e, -10, "hipGetSymbolAddress(pv_scratch) returned a null address on device %d", dev);
+        g_scratch_addr[dev] = static_cast<float*>(p);
+    }
+    *out = g_scratch_addr[dev];
+    return 0;
+}
 
 int alloc3(pvae_engine* e, Buf3& b, int64_t n) {
     b.n = n;
@@ -772,12 +800,8 @@ int begin_batch(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
     if (!e->geno) return set_err(e, -3, "no genotypes loaded (pvae_load_genotypes)");
     if ((rc = check_rows(e, rows, n))) return rc;
     if ((rc = ensure_rows(e, 64))) return rc;
-    pvae_engine::Slot& sl = e->slots[e->slot_next];
+    pvae_engine::Slot& sl = e->slots[e->slot_next];  // pinned ring, allocated by pvae_create
     e->slot_next = (e->slot_next + 1) % 8;
-    if (!sl.host) {
-        HIPCHK(hipHostMalloc((void**)&sl.host, kSlotBytes, hipHostMallocDefault));
-        HIPCHK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-    }
     if (sl.pending) HIPCHK(hipEventSynchronize(sl.ev));
     memcpy(sl.host, rows, n * sizeof(int));
     if (eps) memcpy(sl.host + 32 * sizeof(int), eps, (size_t)n * e->K * sizeof(float));
@@ -804,8 +828,9 @@ int begin_batch(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
 
 int fetch_out3(pvae_engine* e, float* out3) {
     if (!out3) return 0;
-    HIPCHK(hipMemcpyAsync(out3, e->d_loss, 3 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_out3, e->d_loss, 3 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    memcpy(out3, e->h_out3, 3 * sizeof(float));
     return 0;
 }
 
@@ -1128,6 +1153,12 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     HK(hipMemsetAsync(e->d_counter, 0, sizeof(uint64_t), e->stream));
     CK(ensure_rows(e, 4096));
     CK(ensure_loss(e, 1024));
+    for (auto& sl : e->slots) {
+        HK(hipHostMalloc((void**)&sl.host, kSlotBytes, hipHostMallocDefault));
+        HK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    }
+    HK(hipHostMalloc((void**)&e->h_out3, 4 * sizeof(float), hipHostMallocDefault));
+    CK(scratch_address(e, e->dev, &e->scratch));
     e->fused_narrow = e->Wp <= 128 && 2 * e->D + 2 <= PVN_MAXOPS && !getenv("PVAE_NO_FUSED_NARROW");
     e->narrow_warm = !getenv("PVAE_NO_NARROW_WARM");
     CK(build_bwd_ops(e, false, &e->d_bwd_ops));  // also allocates the operand-order copies the forward table points to
@@ -1161,6 +1192,7 @@ int pvae_destroy(pvae_engine* e) {
     hipFree(e->Xt); hipFree(e->geno); hipFree(e->st); hipFree(e->d_rows); hipFree(e->d_ntotal); hipFree(e->d_counter);
     for (auto& ev : e->evs) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     for (auto& sl : e->slots) { if (sl.host) hipHostFree(sl.host); if (sl.ev) hipEventDestroy(sl.ev); }
+    if (e->h_out3) hipHostFree(e->h_out3);
     if (e->own_stream) hipStreamDestroy(e->own_stream);
     delete e;
     return 0;
@@ -1277,6 +1309,33 @@ int pvae_eval_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* 
 }
 int pvae_grad_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3) {
     return full_step(e, rows, n, eps, out3, 2);
+}
+
+int pvae_train_step_noalloc(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3) {
+    // pvae_train_step with the wide kernels' partial sums in the file-scope device array pv_scratch: no hipMalloc,
+    // hipHostMalloc, hipFree or event creation on this path (rows / eps / out3 travel through the pinned ring and the
+    // staging word pvae_create allocated; every device buffer is the engine's own or pv_scratch).
+    if (n <= 0 || n > 32)
+        return set_err(e, -2, "pvae_train_step_noalloc takes one device pass of 1..32 rows (got %d); larger batches run as "
+                              "tiles with gradient dumps that pvae_train_step allocates on first use", n);
+    if (e->cfg.world != 1 || e->comm)
+        return set_err(e, -5, "pvae_train_step_noalloc: SNP-sharded engines exchange through RCCL, which allocates");
+    if (e->timing) return set_err(e, -6, "pvae_train_step_noalloc: switch event timing off first (events are created on demand)");
+    auto al = [](size_t floats) { return (floats + 63) / 64 * 64; };  // 256-byte steps
+    const size_t n_enc = al((size_t)std::max(e->enc_wgs, e->encb_wgs) * e->NWB * 1024);
+    const size_t n_dg = al((size_t)e->dec_wgs * 32 * e->Wp), n_loss = al((size_t)std::max(e->dec_wgs, e->dec_eval_wgs));
+    const size_t need = (n_enc + n_dg + n_loss) * sizeof(float);
+    if (need > PV_SCRATCH_BYTES)
+        return set_err(e, -8, "pvae_train_step_noalloc: this model's partial-sum buffers need %zu bytes, the static scratch "
+                              "array holds %u", need, (unsigned)PV_SCRATCH_BYTES);
+    // nothing in the scratch has to start at zero: every workgroup writes its whole partial before the reduction reads it
+    float *s_enc = e->encpart, *s_dg = e->dgpart, *s_loss = e->losspart;
+    e->encpart = e->scratch;
+    e->dgpart = e->scratch + n_enc;
+    e->losspart = e->scratch + n_enc + n_dg;
+    const int rc = full_step(e, rows, n, eps, out3, 0);
+    e->encpart = s_enc; e->dgpart = s_dg; e->losspart = s_loss;
+    return rc;
 }
 
 int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const int32_t* val_rows, int32_t n_val,
@@ -1585,10 +1644,6 @@ int pvae_stage_c_next(pvae_engine* e, int mode, float* out3, const int32_t* next
     if ((rc = ensure_loss(e, 1))) return rc;
     pvae_engine::Slot& sl = e->slots[e->slot_next];
     e->slot_next = (e->slot_next + 1) % 8;
-    if (!sl.host) {
-        HIPCHK(hipHostMalloc((void**)&sl.host, kSlotBytes, hipHostMallocDefault));
-        HIPCHK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-    }
     if (sl.pending) HIPCHK(hipEventSynchronize(sl.ev));
     memcpy(sl.host, next_rows, (size_t)next_n * sizeof(int));
     HIPCHK(hipMemcpyAsync(e->d_rows + 32, sl.host, (size_t)next_n * sizeof(int), hipMemcpyHostToDevice, e->stream));

@@ -18,7 +18,7 @@ ENGINE_SYMBOLS = [
     "pvae_version", "pvae_device_count", "pvae_create", "pvae_destroy", "pvae_last_error", "pvae_set_stream",
     "pvae_synchronize", "pvae_load_genotypes", "pvae_num_tensors", "pvae_tensor_shape", "pvae_set_tensor",
     "pvae_get_tensor", "pvae_init_weights", "pvae_get_moment", "pvae_reset_optimizer", "pvae_set_lr", "pvae_get_lr",
-    "pvae_train_step", "pvae_eval_step", "pvae_grad_step", "pvae_get_grad", "pvae_train_epoch", "pvae_encode",
+    "pvae_train_step", "pvae_train_step_noalloc", "pvae_eval_step", "pvae_grad_step", "pvae_get_grad", "pvae_train_epoch", "pvae_encode",
     "pvae_decode", "pvae_pca_gram", "pvae_snapshot_best", "pvae_restore_best", "pvae_exchange_buffer", "pvae_exchange_copy", "pvae_stage_a", "pvae_stage_b",
     "pvae_stage_c", "pvae_stage_c_next", "pvae_stage_encode", "pvae_set_timing", "pvae_get_timing", "pvae_set_timing_only",
     "pvae_comm_unique_id", "pvae_comm_init", "pvae_comm_allreduce", "pvae_comm_destroy",
@@ -66,7 +66,7 @@ def lib():
         L.pvae_reset_optimizer.argtypes = [vp]
         L.pvae_set_lr.argtypes = [vp, C.c_float]
         L.pvae_get_lr.argtypes = [vp, C.POINTER(C.c_float)]
-        for f in (L.pvae_train_step, L.pvae_eval_step, L.pvae_grad_step):
+        for f in (L.pvae_train_step, L.pvae_train_step_noalloc, L.pvae_eval_step, L.pvae_grad_step):
             f.argtypes = [vp, _i32p, i32, _fopt, _fopt]
         L.pvae_get_grad.argtypes = [vp, C.c_int, _f32p, i64]
         L.pvae_train_epoch.argtypes = [vp, _i32p, i32, _i32p, i32, _fopt, _fopt]
@@ -218,6 +218,10 @@ class Engine:
 
     def train_step(self, rows, eps=None, want_loss=True):
         return self._step(lib().pvae_train_step, rows, eps, want_loss)
+
+    def train_step_noalloc(self, rows, eps=None, want_loss=True):
+        """``train_step`` for callers that cannot allocate: partial sums in the library's static device array."""
+        return self._step(lib().pvae_train_step_noalloc, rows, eps, want_loss)
 
     def eval_step(self, rows, eps=None, want_loss=True):
         return self._step(lib().pvae_eval_step, rows, eps, want_loss)
