@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=71)   # one C4 epoch = 71 train steps
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (exactly --steps steps between barriers) is run this many times; `value` and "
+                         "`ms_per_step` are the MEDIAN repetition, min / max are reported next to them")
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
@@ -184,27 +187,31 @@ def main():
 
     run(batches(args.warmup)) if args.warmup > 0 else None
     barrier()
-    rows_timed = batches(args.steps)
     # HIP events on the engine's stream, live over the timed region, around the dominant kernel only: an event pair
     # costs the stream ~5-10 us per launch, and events around all six kernel categories would take ~3 % off `value`
     eng.set_timing(True, only="dec")
-    barrier()
-    t0 = time.perf_counter()
-    run(rows_timed)
-    eng.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    reps = []
+    for _ in range(max(1, args.repeats)):
+        rows_timed = batches(args.steps)
+        barrier()
+        t0 = time.perf_counter()
+        run(rows_timed)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        reps.append(dt)
+    elapsed = float(np.median(reps))
     dec_timed = eng.get_timing("dec")
     # per-kernel breakdown of the other categories: a second, untimed pass of 20 steps with events around everything
     eng.set_timing(True)
     run(batches(20))
     barrier()
     kern = {}
-    for name in ("gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd"):
+    for name in ("gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd", "xch0", "xch1"):
         ms, n = eng.get_timing(name)
         kern[name] = (ms, n)
     kern["dec"] = dec_timed
@@ -262,10 +269,12 @@ def main():
                     kernels[k]["frac_hbm_peak"] = kernels[k]["GBps"] / HBM_PEAK_GBS
         # measured HBM traffic (rocprofv3 PMC, committed under profiles/) for the same kernel and workload
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic_C4.json")
-        if args.workload == "C4" and world == 1 and os.path.exists(tf):
-            traffic = json.load(open(tf))["kernels"].get("dec", {}).get("traffic_bytes")
-            traffic_src = "profiles/r01_pmc_traffic_C4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        import glob
+        tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{args.workload}.json")))
+        if world == 1 and tfs:
+            traffic = json.load(open(tfs[-1]))["kernels"].get("dec", {}).get("traffic_bytes")
+            traffic_src = (f"profiles/{os.path.basename(tfs[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                           "FETCH_SIZE doubled per MI355X_MICROARCH.md)")
         ach = kernels.get("dec", {}).get("GBps", 0.0)
         n_train = int(0.9 * N)
         st_tr, st_va = -(-n_train // B), -(-(N - n_train) // B)
@@ -273,6 +282,8 @@ def main():
         out = {
             "metric": "train_samples_per_sec", "value": args.steps * B / elapsed, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "repeats": len(reps), "statistic": "median over the repetitions of the timed region",
+            "ms_per_step_min": min(reps) * 1e3 / args.steps, "ms_per_step_max": max(reps) * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if backend == "nccl" else f"synthetic; REHEARSAL over {backend}, ranks share GPUs: not a measurement",
             "config": {"workload": f"{args.workload}: {N} samples x {L} SNPs, depth {D}, width {W}, latent {K}, "
@@ -286,7 +297,9 @@ def main():
                          "algorithmic_bytes_per_launch": algo["dec"],
                          "avg_launch_ms": kernels.get("dec", {}).get("ms")},
             "kernels": kernels,
-            "kernels_note": "dec: HIP events over the timed region; the others: a separate untimed pass of 20 steps",
+            "kernels_note": "dec: HIP events over the timed repetitions; the others (and xch0 / xch1, the two all-reduces of a "
+                            "step on the engine-owned communicator): a separate untimed pass of 20 steps",
+            "comm": step_engine.comm_report() if sharded else None,
             "epochs_per_sec": 1e3 / epoch_ms if epoch_ms else 1.0 / ((st_tr * ms_per_step + st_va * val_ms) * 1e-3),
             "epochs_per_sec_note": (f"measured: 3 whole epochs ({st_tr} train + {st_va} validation steps each) through the "
                                     "C-side epoch loop" if epoch_ms else "composed from ms_per_step and val_ms_per_step"),

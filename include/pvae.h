@@ -150,13 +150,17 @@ int pvae_stage_encode(pvae_engine* e, int32_t n, float* z_mean, float* z_log_var
  * stages (in place on the exchange buffers; next-batch forward fused as on one GPU).  librccl is bound with dlopen at the
  * first call, so a process that already holds one (PyTorch's) keeps using that one.  pvae_comm_allreduce runs one such
  * all-reduce by itself (self-test; host-driven staging).  No counterpart in the reference (it has no multi-GPU path). */
+int pvae_comm_available(void); /* 1 when librccl could be bound (checked by every rank BEFORE the collective pvae_comm_init) */
 int pvae_comm_unique_id(char* id128);
 int pvae_comm_init(pvae_engine* e, const char* id128);
+/* what the communicator itself reports (ncclCommCount / ncclCommUserRank): bench.py prints it on the --gpus N line */
+int pvae_comm_info(pvae_engine* e, int32_t* nranks, int32_t* rank);
 int pvae_comm_allreduce(pvae_engine* e, int which);
 int pvae_comm_destroy(pvae_engine* e);
 
 /* measurement hook: average device time (ms) of the last call's kernels by name, via hipEvents on the
- * engine stream; names: "enc_fwd", "dec", "enc_bwd", "narrow_fwd", "narrow_bwd", "gather" */
+ * engine stream; names: "enc_fwd", "dec", "enc_bwd", "narrow_fwd", "narrow_bwd", "gather", and "xch0" / "xch1" = the two
+ * all-reduces of a step on the engine-owned communicator */
 int pvae_set_timing(pvae_engine* e, int enabled);
 int pvae_get_timing(pvae_engine* e, const char* name, float* ms_total, int64_t* launches);
 /* as pvae_set_timing(e, 1), but only the named category gets events: every event pair costs the stream ~5-10 us per

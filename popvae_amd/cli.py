@@ -51,6 +51,9 @@ def build_parser():
     p.add_argument("--test", default=False, action="store_true", help="fit with the test data")
     p.add_argument("--plot", default=False, action="store_true")
     p.add_argument("--metadata", default=None, help="path to tab-delimited metadata file with column 'sampleID'.")
+    # not a flag of the reference: start from exported weights (a Keras <out>_weights.hdf5 / .npz), for per-step parity runs
+    p.add_argument("--init_weights", default=None,
+                   help="(popvae_amd) initialise the model from a Keras weight file (.hdf5) or .npz instead of glorot_uniform")
     return p
 
 
@@ -58,13 +61,8 @@ def load_genotypes(infile, rng, save_allele_counts=False, log=print):
     """popvae.py:195-248 -> (packed 2-bit matrix [N][row_bytes], n_snps, samples)."""
     from . import prep
     if infile.endswith(".popvae.hdf5"):
-        try:
-            import h5py
-        except ImportError as ex:
-            raise RuntimeError(".popvae.hdf5 input needs h5py, which is not importable here") from ex
-        with h5py.File(infile, "r") as h5:
-            dc = np.array(h5["derived_counts"])
-            samples = np.array([s.decode() if isinstance(s, bytes) else s for s in np.array(h5["samples"])], dtype=object)
+        from .weights_io import read_popvae_cache
+        dc, samples = read_popvae_cache(infile)  # popvae.py:205-209 (plain-Python HDF5 reader, no h5py needed)
         return prep.pack_dc(dc), dc.shape[1], samples
     if infile.endswith(".zarr"):
         try:
@@ -85,42 +83,9 @@ def load_genotypes(infile, rng, save_allele_counts=False, log=print):
     packed, n_snps, _, _, _ = prep.filter_impute_pack(gen, rng)
     if save_allele_counts:
         log("saving derived counts for reanalysis")
-        try:
-            import h5py
-        except ImportError as ex:
-            raise RuntimeError("--save_allele_counts needs h5py, which is not importable here") from ex
-        with h5py.File(infile + ".popvae.hdf5", "w") as outfile:
-            outfile.create_dataset("derived_counts", data=prep.unpack_dc(packed, n_snps))
-            outfile.create_dataset("samples", data=[str(s) for s in samples], dtype=h5py.string_dtype())
+        from .weights_io import write_popvae_cache
+        write_popvae_cache(infile + ".popvae.hdf5", prep.unpack_dc(packed, n_snps), samples)
     return packed, n_snps, samples
-
-
-def save_weights_file(path_stem, weights, names):
-    """``--save_weights`` (popvae.py:429-435,525-526): Keras ``model_weights`` layout when h5py is importable,
-    otherwise ``<stem>_weights.npz`` with the same tensor names."""
-    try:
-        import h5py
-    except ImportError:
-        np.savez(path_stem + "_weights.npz", **{n.replace("/", "__"): w for n, w in zip(names, weights)})
-        return path_stem + "_weights.npz"
-    with h5py.File(path_stem + "_weights.hdf5", "w") as f:
-        grp = f.create_group("model_weights")
-        for n, w in zip(names, weights):
-            layer, var = n.split("/")
-            g = grp.require_group(layer).require_group(layer)
-            g.create_dataset(var + ":0", data=w)
-    return path_stem + "_weights.hdf5"
-
-
-def tensor_names(depth):
-    names = []
-    for i in range(depth):
-        names += [f"enc_dense{i}/kernel", f"enc_dense{i}/bias"]
-    names += ["z_mean/kernel", "z_mean/bias", "z_log_var/kernel", "z_log_var/bias"]
-    for i in range(depth):
-        names += [f"dec_dense{i}/kernel", f"dec_dense{i}/bias"]
-    names += ["dec_out/kernel", "dec_out/bias"]
-    return names
 
 
 def main(argv=None):
@@ -167,6 +132,11 @@ def main(argv=None):
         else:
             dist.init_process_group(backend)
 
+    host_pg = None
+    if world > 1:  # Python objects (grid results, weight shards) travel over a CPU group with a day-long timeout
+        import datetime
+        host_pg = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=24))
+
     seed = args.seed
     if seed is not None:
         os.environ["PYTHONHASHSEED"] = str(seed)
@@ -192,6 +162,11 @@ def main(argv=None):
     train, test = prep.train_test_split(ninds, args.train_prop, rng)
     log("validation samples:" + np.asarray(samples, dtype=object)[test])
     log("running on " + str(n_snps) + " SNPs")
+    if n_snps * 1e-3 > 300:
+        # not a change of behaviour: the reference (Keras Adam, lr 1e-3) does the same
+        log(f"WARNING: with {n_snps} SNPs the first Adam steps at Keras' default learning rate 1e-3 move the first layer's "
+            "pre-activations by ~n_snps * lr; float32 exp(z_log_var) was seen to overflow (loss = nan) from the second step "
+            "at 1M SNPs.  If the loss turns nan, thin the input with --max_SNPs.")
 
     eng_seed = run_seed
     shuffle_seed = run_seed
@@ -208,9 +183,12 @@ def main(argv=None):
         log("running grid search on network sizes")
         gather = None
         if world > 1:
+            # every rank runs a different set of cells, and early stopping makes their run times data dependent: the
+            # results meet over a CPU (gloo) group with a day-long timeout, not in a RCCL collective under the process
+            # group watchdog's 10 minutes
             def gather(obj):
                 outl = [None] * world
-                dist.all_gather_object(outl, obj)
+                dist.all_gather_object(outl, obj, group=host_pg)
                 return outl
         _, width, depth = F.grid_search(make_single, width_range, depth_range, train, test, args.max_epochs,
                                         args.patience, n_snps, out=args.out,
@@ -227,6 +205,10 @@ def main(argv=None):
         eng.init_weights(eng_seed)
     else:
         eng = make_single(width, depth)
+    if args.init_weights:  # vae.load_weights before fit (per-step parity from a Keras export)
+        from .weights_io import load_weights_file
+        log("initialising from " + args.init_weights)
+        eng.set_weights(load_weights_file(args.init_weights))
 
     t1 = time.time()
     history, cbs = F.fit(eng, train, test, max_epochs=args.max_epochs, patience=args.patience,
@@ -241,13 +223,14 @@ def main(argv=None):
     # popvae.py:507-523: best weights -> latent coordinates of all samples
     eng.restore_best()
     pred = eng.encode(np.arange(ninds, dtype=np.int32))
+    full_weights = None
+    if args.save_weights:  # under sharding the SNP-axis tensors are gathered to rank 0 (collective: every rank calls it)
+        full_weights = eng.get_weights_full(host_pg) if world > 1 else eng.get_weights()
     if rank == 0:
         F.write_latent_coords(args.out + "_latent_coords.txt", pred, samples, args.latent_dim)
-        if args.save_weights:
-            if world > 1:
-                log("--save_weights: each rank holds an SNP shard; writing rank 0's shard only")
-            w = eng.get_weights_shard() if world > 1 else eng.get_weights()
-            log("weights saved to " + save_weights_file(args.out, w, tensor_names(depth)))
+        if args.save_weights and full_weights is not None:  # popvae.py:429-435, 525-526: the best epoch's weights stay on disk
+            from .weights_io import save_weights_hdf5
+            log("weights saved to " + save_weights_hdf5(args.out + "_weights.hdf5", full_weights, depth))
         try:
             F.plot_history(args.out + "_history.pdf", history)
         except Exception as ex:  # matplotlib absent or headless failure: the reference's pdf is cosmetic

@@ -64,8 +64,8 @@ struct TensorRef {
     int64_t rows, cols;  // Keras shape (cols = 0 for bias)
 };
 
-enum Cat { C_GATHER, C_ENC_FWD, C_NARROW_FWD, C_DEC, C_NARROW_BWD, C_ENC_BWD, C_NCAT };
-const char* kCatNames[C_NCAT] = {"gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd"};
+enum Cat { C_GATHER, C_ENC_FWD, C_NARROW_FWD, C_DEC, C_NARROW_BWD, C_ENC_BWD, C_XCH0, C_XCH1, C_NCAT };
+const char* kCatNames[C_NCAT] = {"gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd", "xch0", "xch1"};
 
 }  // namespace
 
@@ -363,6 +363,8 @@ struct PvRccl {
     int (*GetUniqueId)(PvNcclId*) = nullptr;
     int (*CommInitRank)(void**, int, PvNcclId, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string err;
@@ -382,10 +384,14 @@ PvRccl* rccl() {
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.lib, "ncclCommUserRank");
     r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
-        r.err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce / ncclGetErrorString";
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString || !r.CommCount ||
+        !r.CommUserRank) {
+        r.err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce / ncclGetErrorString / "
+                "ncclCommCount / ncclCommUserRank";
         r.lib = nullptr;
     }
     return &r;
@@ -397,6 +403,7 @@ int shard_allreduce(pvae_engine* e, int which) {
                                         "pvae_stage_a/b/c with all-reduces in between");
     float* buf = which == 0 ? e->P : e->xch1;
     const size_t n = which == 0 ? (size_t)32 * e->Wp : (size_t)32 * e->Wp + 32;
+    Timer t(e, which == 0 ? C_XCH0 : C_XCH1);
     const int rc = rccl()->AllReduce(buf, buf, n, 7 /* ncclFloat32 */, 0 /* ncclSum */, e->comm, e->stream);
     if (rc) return set_err(e, -12, "ncclAllReduce: %s", rccl()->GetErrorString(rc));
     return 0;
@@ -1662,6 +1669,8 @@ int pvae_comm_unique_id(char* id128) {
     memcpy(id128, id.internal, 128);
     return 0;
 }
+int pvae_comm_destroy(pvae_engine* e);
+int pvae_comm_info(pvae_engine* e, int32_t* nranks, int32_t* rank);
 int pvae_comm_init(pvae_engine* e, const char* id128) {
     PvRccl* r = rccl();
     if (!r->lib) return set_err(e, -12, "%s", r->err.c_str());
@@ -1674,6 +1683,23 @@ int pvae_comm_init(pvae_engine* e, const char* id128) {
     const int rc = r->CommInitRank(&comm, e->cfg.world, id, e->cfg.rank);
     if (rc) return set_err(e, -12, "ncclCommInitRank: %s", r->GetErrorString(rc));
     e->comm = comm;
+    // what RCCL itself saw must be what the configuration says (the struct travels by value through a dlsym'd pointer)
+    int32_t n = 0, me = -1;
+    if (pvae_comm_info(e, &n, &me)) { pvae_comm_destroy(e); return -12; }
+    if (n != e->cfg.world || me != e->cfg.rank) {
+        pvae_comm_destroy(e);
+        return set_err(e, -12, "communicator reports rank %d of %d, configuration says %d of %d", me, n, e->cfg.rank, e->cfg.world);
+    }
+    return 0;
+}
+int pvae_comm_available(void) { return rccl()->lib ? 1 : 0; }
+int pvae_comm_info(pvae_engine* e, int32_t* nranks, int32_t* rank) {
+    if (!e->comm) return set_err(e, -12, "no communicator (pvae_comm_init)");
+    int n = 0, r = -1, rc;
+    if ((rc = rccl()->CommCount(e->comm, &n))) return set_err(e, -12, "ncclCommCount: %s", rccl()->GetErrorString(rc));
+    if ((rc = rccl()->CommUserRank(e->comm, &r))) return set_err(e, -12, "ncclCommUserRank: %s", rccl()->GetErrorString(rc));
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
     return 0;
 }
 int pvae_comm_allreduce(pvae_engine* e, int which) {

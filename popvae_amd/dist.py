@@ -6,14 +6,14 @@ the first encoder kernel, columns of the last decoder kernel, output-bias entrie
 the same columns of the genotype matrix.  The narrow layers are replicated and computed redundantly.
 Per train step there are exactly two small SUM all-reduces (default: enqueued by the engine itself on its stream through
 its own RCCL communicator, ``pvae_comm_init`` -- no host code inside the step; ``PVAE_COMM=torch`` or a failed
-self-test selects the host-driven staged path over ``torch.distributed`` instead):
+set-up, agreed on by all ranks, selects the host-driven, host-staged path over ``torch.distributed`` instead):
 
   1. partial first-layer sums  X_r . W1_r           [32 x width]        (after stage A)
   2. partial decoder feedback  dg_D (and BCE sum)   [32 x width + 32]   (after stage B)
 
 All ranks receive bit-identical reduced buffers, so the replicated narrow layers stay bit-identical
-without any gradient all-reduce.  RCCL is reached through torch.distributed (backend "nccl"); "gloo"
-works too (CPU tests, or several ranks sharing one GPU).
+without any gradient all-reduce.  The fallback path works over any torch.distributed backend ("nccl" = RCCL; "gloo":
+CPU tests, or several ranks sharing one GPU).
 """
 from __future__ import annotations
 
@@ -48,14 +48,6 @@ def shard_packed(packed, n_snps, lo, hi):
     return out
 
 
-class _DevArray:
-    """Zero-copy view of an engine-owned device buffer for torch (``__cuda_array_interface__``)."""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False),
-                                         "version": 2}
-
-
 class ShardedEngine:
     """Same host interface as ``Engine`` for a model whose SNP axis is split over ``dist`` ranks."""
 
@@ -81,42 +73,48 @@ class ShardedEngine:
         import os
         self.device_id = int(device_id)
         self._trace = bool(os.environ.get("PVAE_DIST_TRACE"))  # debugging aid: progress line around every host-driven exchange
-        # host-driven exchanges are bracketed by host syncs (see _allreduce); PVAE_DIST_STREAM_ORDERED=1 selects the
-        # stream-ordered variant under RCCL (engine on torch's current stream, no host sync inside a step)
-        self._host_sync = dist.is_initialized() and not (dist.get_backend(process_group) == "nccl"
-                                                         and os.environ.get("PVAE_DIST_STREAM_ORDERED"))
-        self._host_staged = (dist.is_initialized() and dist.get_backend(process_group) != "nccl"
-                             and hasattr(self.eng, "exchange_read"))
+        # The host-driven exchange is host-staged for EVERY backend (see _allreduce): the engine never shares a stream,
+        # an event or a device pointer with torch.distributed.
+        self._staged = hasattr(self.eng, "exchange_read")          # test doubles hand out CPU tensors instead
+        self._cuda_collectives = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self.comm_note = "single rank"
         self.native = self._init_native_comm()
-        self._bufs = [self._wrap(*self.eng.exchange_buffer(i), device_id) for i in (0, 1)]
+        self._bufs = None if self._staged else [self.eng.exchange_buffer(i)[0] for i in (0, 1)]
         try:  # test doubles (CPU stand-in engines) take no next_rows
             import inspect
             self._can_fuse = "next_rows" in inspect.signature(self.eng.stage_c).parameters
         except (TypeError, ValueError):
             self._can_fuse = False
-        # With its own communicator the engine keeps its own (non-blocking) stream and torch is not involved in a step at
-        # all.  Otherwise the exchanges run on a dedicated non-blocking torch stream (which is also the engine's stream in
-        # the stream-ordered variant) and never touch torch's legacy default stream, whose implicit synchronisation with
-        # every blocking stream of the process the dead-lock described in _allreduce hinged on.
-        self._xs = None
-        if not self.native and hasattr(self.eng, "set_stream") and torch.cuda.is_available():
-            self._xs = torch.cuda.Stream(device=device_id)
-            if not self._host_sync:
-                self.eng.set_stream(self._xs.cuda_stream)
+
+    def _agree(self, ok):
+        """MIN over the ranks of a 0/1 flag (on the host for gloo, on the device for RCCL)."""
+        flag = self._torch.tensor([int(bool(ok))], dtype=self._torch.int32)
+        if self._cuda_collectives:
+            flag = flag.to(f"cuda:{self._torch.cuda.current_device()}")
+        self._dist.all_reduce(flag, op=self._dist.ReduceOp.MIN, group=self.pg)
+        return bool(int(flag.item()))
 
     def _init_native_comm(self):
-        """Engine-owned RCCL communicator: rank 0 draws the unique id, torch.distributed carries the 128 bytes, every rank
-        joins, one all-reduce of (rank + 1) on exchange buffer 0 checks the ring, and the ranks agree (MIN over a flag) on
-        using it.  Anything short of that leaves the host-driven path in place."""
+        """Engine-owned RCCL communicator, set up by agreement at every step that can fail on one rank alone:
+
+        1. the ranks compare device identities (RCCL wants one device per rank);
+        2. every rank checks that librccl can be bound (``comm_available``) and the ranks agree -- BEFORE anyone enters
+           the collective ncclCommInitRank, where a rank whose peers never arrive would wait forever;
+        3. rank 0 draws the unique id, torch.distributed carries the 128 bytes, every rank joins (the engine checks
+           ncclCommCount / ncclCommUserRank against its configuration);
+        4. one all-reduce of (rank + 1) on exchange buffer 0 checks the ring, and the ranks agree on the outcome.
+
+        Anything short of that leaves the host-driven path in place on ALL ranks (a communicator that some rank did build
+        is destroyed again).  ``PVAE_COMM_INJECT_FAIL=<rank>|all`` makes step 2 fail on that rank (tests);
+        ``PVAE_COMM_ASSUME_DISTINCT=1`` skips step 1 (tests on a one-GPU box, together with the injected failure)."""
         import os
         dist = self._dist
-        if os.environ.get("PVAE_COMM", "rccl").lower() == "torch" or not hasattr(self.eng, "comm_init"):
-            return False
         if not (self.world > 1 or self.force_collectives) or not dist.is_initialized():
             return False
-        # RCCL wants one device per rank: two ranks on one GPU (tests, rehearsals) would fail inside ncclCommInitRank and leave
-        # half-built communicator state behind (later collectives of the process were seen to hang), so the ranks compare
-        # device identities first and do not try
+        self.comm_note = "host-staged all-reduces over torch.distributed"
+        if os.environ.get("PVAE_COMM", "rccl").lower() == "torch" or not hasattr(self.eng, "comm_init"):
+            self.comm_note += " (PVAE_COMM=torch)" if hasattr(self.eng, "comm_init") else ""
+            return False
         import socket
         try:
             uid = str(self._torch.cuda.get_device_properties(self.device_id).uuid)
@@ -126,7 +124,16 @@ class ShardedEngine:
                  self.device_id)
         idents = [None] * self.world
         dist.all_gather_object(idents, ident, group=self.pg)
-        if len(set(idents)) < self.world:
+        if len(set(idents)) < self.world and not os.environ.get("PVAE_COMM_ASSUME_DISTINCT"):
+            self.comm_note += " (ranks share a device: RCCL wants one per rank)"
+            return False
+        inject = os.environ.get("PVAE_COMM_INJECT_FAIL", "")
+        try:
+            ok = type(self.eng).comm_available() and inject not in ("all", str(self.rank))
+        except Exception:
+            ok = False
+        if not self._agree(ok):
+            self.comm_note += " (librccl not usable on some rank)"
             return False
         box = [None]
         if self.rank == 0:
@@ -136,61 +143,62 @@ class ShardedEngine:
                 box[0] = None
         dist.broadcast_object_list(box, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
         if box[0] is None:
+            self.comm_note += " (ncclGetUniqueId failed)"
             return False
-        ok = 1
+        ok = True
         try:
             self.eng.comm_init(box[0])
             n = self.eng.exchange_buffer(0)[1]
             self.eng.exchange_write(0, np.full(n, self.rank + 1, np.float32))
             self.eng.comm_allreduce(0)
             got = self.eng.exchange_read(0)
-            if not np.all(got == np.float32(self.world * (self.world + 1) // 2)):
-                ok = 0
+            ok = bool(np.all(got == np.float32(self.world * (self.world + 1) // 2)))
         except Exception:
-            ok = 0
-        flag = self._torch.tensor([ok], dtype=self._torch.int32)
-        backend = dist.get_backend(self.pg)
-        if backend == "nccl":
-            flag = flag.to(f"cuda:{self._torch.cuda.current_device()}")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
-        return bool(int(flag.item()))
+            ok = False
+        if not self._agree(ok):
+            try:
+                self.eng.comm_destroy()
+            except Exception:
+                pass
+            self.comm_note += " (communicator self-test failed on some rank)"
+            return False
+        nr, me = self.eng.comm_info()
+        self.comm_note = f"engine-owned RCCL communicator, rank {me} of {nr} (ncclCommCount)"
+        return True
 
-    def _wrap(self, ptr, n, device_id):
-        if isinstance(ptr, self._torch.Tensor):  # test doubles hand out CPU tensors directly
-            return ptr
-        return self._torch.as_tensor(_DevArray(ptr, n), device=f"cuda:{device_id}")
+    def comm_report(self):
+        """For bench.py's --gpus N line: which exchange path runs and what RCCL itself says about the communicator."""
+        out = {"path": "native" if self.native else ("host-staged" if (self.world > 1 or self.force_collectives) else "none"),
+               "note": self.comm_note, "comm_nranks": None}
+        if self.native:
+            out["comm_nranks"] = self.eng.comm_info()[0]
+        return out
 
     def _allreduce(self, which):
-        if self.world > 1 or self.force_collectives:
-            if self._trace:
-                self._n_ar = getattr(self, "_n_ar", 0) + 1
-                print(f"[dist r{self.rank}] all_reduce #{self._n_ar} buf {which} enter", flush=True)
-            # torch.distributed runs a collective on side streams tied to the current stream by events (gloo adds a worker
-            # thread and host staging).  With engine kernels still queued ahead of the exchange on torch's legacy default
-            # stream this was seen to dead-lock after a few steps (two ranks on one GPU over gloo), so by default the engine
-            # keeps its own stream and every exchange is bracketed by host syncs: this is the fallback path, a few tens of
-            # microseconds per exchange matter less than a hang.
-            # Backends without device-pointer support of their own (gloo) get host buffers: pvae_exchange_copy stages the
-            # exchange buffer through the host (synchronous on the engine's stream), the collective runs on CPU tensors.
-            # gloo's own staging of CUDA tensors hung intermittently here even with the engine idle.
-            if self._host_staged:
-                h = self._torch.from_numpy(self.eng.exchange_read(which))
-                self._dist.all_reduce(h, op=self._dist.ReduceOp.SUM, group=self.pg)
-                self.eng.exchange_write(which, h.numpy())
-                if self._trace:
-                    print(f"[dist r{self.rank}] all_reduce #{self._n_ar} done (host-staged)", flush=True)
-                return
-            if self._host_sync:
-                self.eng.synchronize()
-            if self._xs is not None:
-                with self._torch.cuda.stream(self._xs):
-                    self._dist.all_reduce(self._bufs[which], op=self._dist.ReduceOp.SUM, group=self.pg)
-                if self._host_sync:
-                    self._xs.synchronize()
+        """Host-driven exchange (fallback path; the default is the engine-owned communicator).  Host-staged for every
+        backend: pvae_exchange_copy brings the buffer to the host (synchronous on the engine's stream), the collective runs
+        on a tensor that torch owns (CPU for gloo, a fresh device tensor for RCCL), the sum goes back the same way.  The
+        engine therefore never shares a stream, an event or a device pointer with torch.distributed -- the variant that did
+        (zero-copy views of the engine's buffers on a torch side stream) dead-locked in rehearsals, see DESIGN.md section 6,
+        and was removed."""
+        if not (self.world > 1 or self.force_collectives):
+            return
+        if self._trace:
+            self._n_ar = getattr(self, "_n_ar", 0) + 1
+            print(f"[dist r{self.rank}] all_reduce #{self._n_ar} buf {which} enter", flush=True)
+        if not self._staged:  # test doubles: CPU tensors, reduced in place
+            self._dist.all_reduce(self._bufs[which], op=self._dist.ReduceOp.SUM, group=self.pg)
+        else:
+            h = self._torch.from_numpy(self.eng.exchange_read(which))
+            if self._cuda_collectives:
+                d = h.to(f"cuda:{self.device_id}")
+                self._dist.all_reduce(d, op=self._dist.ReduceOp.SUM, group=self.pg)
+                h = d.cpu()
             else:
-                self._dist.all_reduce(self._bufs[which], op=self._dist.ReduceOp.SUM, group=self.pg)
-            if self._trace:
-                print(f"[dist r{self.rank}] all_reduce #{self._n_ar} done", flush=True)
+                self._dist.all_reduce(h, op=self._dist.ReduceOp.SUM, group=self.pg)
+            self.eng.exchange_write(which, h.numpy())
+        if self._trace:
+            print(f"[dist r{self.rank}] all_reduce #{self._n_ar} done", flush=True)
 
     # -- data / weights ------------------------------------------------------------------------
     def load_genotypes(self, packed_full):
@@ -213,6 +221,25 @@ class ShardedEngine:
 
     def get_weights_shard(self):
         return self.eng.get_weights()
+
+    def get_weights_full(self, group=None):
+        """The whole model in ``vae.get_weights()`` order on rank 0 (None elsewhere): the SNP-axis tensors (first
+        encoder kernel's rows, last decoder kernel's columns, output bias) are gathered from the shards, the replicated
+        ones are rank 0's.  Collective over ``group`` (default: this engine's process group; pass a gloo group when the
+        main one is RCCL -- object collectives pickle through host memory anyway)."""
+        w = self.eng.get_weights()
+        if self.world == 1:
+            return w
+        group = self.pg if group is None else group
+        parts = [None] * self.world if self.rank == 0 else None
+        dst = self._dist.get_global_rank(group, 0) if group is not None else 0
+        self._dist.gather_object((w[0], w[-2], w[-1]), parts, dst=dst, group=group)
+        if self.rank != 0:
+            return None
+        w[0] = np.concatenate([p[0] for p in parts], axis=0)
+        w[-2] = np.concatenate([p[1] for p in parts], axis=1)
+        w[-1] = np.concatenate([p[2] for p in parts], axis=0)
+        return w
 
     @property
     def lr(self):
@@ -282,9 +309,8 @@ class ShardedEngine:
         G = self.eng.pca_gram(scaler)
         if self.world > 1 or self.force_collectives:
             t = self._torch.from_numpy(G)
-            dev = self._bufs[0].device if isinstance(self._bufs[0], self._torch.Tensor) else "cpu"
-            if str(dev) != "cpu" and not self._host_staged:
-                t = t.to(dev)
+            if self._cuda_collectives:
+                t = t.to(f"cuda:{self.device_id}")
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.pg)
             G = t.cpu().numpy()
         return G

