@@ -102,6 +102,9 @@ struct pvae_engine {
     float* scratch = nullptr;      // this device's copy of pv_scratch (hipGetSymbolAddress at pvae_create)
     float* h_out3 = nullptr;       // pinned staging of {loss, recon, kl}
     int enc_wgs = 0, dec_wgs = 0, encb_wgs = 0, dec_eval_wgs = 0;
+    int dec2_wgs = 0;          // plain training pass at widths up to 128: pvk_dec2 (0 = use pvk_dec)
+    int encb_parts = 0;        // partial tiles [32][Wp] the fused forward of pvk_enc_bwd leaves in encpart (one per subtile slot)
+    int64_t encpart_floats = 0;
     int64_t tile_floats = 0;
     int ts4 = 0;
     // fused narrow stack (width <= 128): op tables in device memory
@@ -289,13 +292,11 @@ size_t lds_dense_bwd(int N) { return (size_t)(2 * 32 * (N + 1) + 4096) * 4; }
 size_t lds_dec_eval(int NWB) { return (size_t)(32 * (NWB * 32 + 1) + 64) * 4; }
 size_t lds_dec(int NWB) { return (size_t)(32 * (NWB * 32 + 1) + 4 * 3 * 32 * 33) * 4; }
 size_t lds_enc_bwd(int Wp) { return (size_t)32 * Wp * 4; }
-size_t lds_enc_bwd_fused(int NWB, int Wp) { return std::max<size_t>((size_t)32 * Wp * 4, (size_t)4 * NWB * 1024 * 4); }
 constexpr int dec_grp_waves(int ngrp) { return ngrp == 2 ? 4 : 8; }  // waves per workgroup of pvk_dec_grp
 size_t lds_dec_grp(int ngrp) {
     const size_t nw = dec_grp_waves(ngrp);
     return std::max<size_t>((size_t)32 * (ngrp * 128 + 1) + nw * 2 * 32 * 33, nw * 4 * 1024 + nw) * 4;
 }
-size_t lds_enc_fwd(int NWB) { return (size_t)4 * NWB * 1024 * 4; }
 
 template <typename Kern>
 hipError_t allow_lds(Kern k, size_t bytes) {
@@ -311,13 +312,13 @@ int setup_kernel_attrs(pvae_engine* e) {
     HIPCHK(allow_lds(pvk_narrow_bwd<PV_MODE_GRAD>, pvn_lds_bwd()));
     HIPCHK(allow_lds(pvk_narrow_bwd<PV_MODE_TRAIN_ACC>, pvn_lds_bwd()));
 #define PV_ATTR(N)                                                                    \
-    HIPCHK(allow_lds(pvk_enc_fwd<N>, lds_enc_fwd(N)));                                \
+    HIPCHK(allow_lds(pvk_dec2<N>, PvDec2<N>::lds()));                                 \
     HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_TRAIN>, lds_dec(N)));                      \
     HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_GRAD>, lds_dec(N)));                       \
     HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_TRAIN_ACC>, lds_dec(N)));                  \
     HIPCHK(allow_lds(pvk_dec<N, 0, PV_MODE_TRAIN>, lds_dec(N)));                      \
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN, 0>), lds_enc_bwd(e->Wp)));        \
-    HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN, 1>), lds_enc_bwd_fused(N, e->Wp)));  \
+    HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN, 1>), lds_enc_bwd(e->Wp)));        \
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_GRAD, 0>), lds_enc_bwd(e->Wp)));         \
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN_ACC, 0>), lds_enc_bwd(e->Wp)));
     switch (e->NWB) {
@@ -441,15 +442,15 @@ int stage_a(pvae_engine* e, int row_offset, bool need_xt, bool fwd_done = false)
     }
     if (fwd_done) {
         // the previous step's pvk_enc_bwd<.., FUSE = 1> already left this batch's partial sums in encpart
-        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(32 * e->Wp)), dim3(256), 0, e->stream, e->encpart, e->encb_wgs / e->ngrp,
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(32 * e->Wp)), dim3(256), 0, e->stream, e->encpart, e->encb_parts,
                            32 * e->Wp, 0.5f, e->P, (const float*)nullptr, (float*)nullptr);
         if ((rc = launch_check(e, "enc_reduce"))) return rc;
     } else {
         Timer t(e, C_ENC_FWD);
-        PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_enc_fwd<N_>, dim3(e->enc_wgs), dim3(256), lds_enc_fwd(N_), e->stream, e->W1.w, e->geno,
+        PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_enc_fwd<N_>, dim3(e->enc_wgs), dim3(256), 0, e->stream, e->W1.w, e->geno,
                                               e->row_bytes, e->d_rows, e->st, row_offset, e->nblk, e->ngrp, e->encpart, e->ts4));
         if ((rc = launch_check(e, "enc_fwd"))) return rc;
-        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(32 * e->Wp)), dim3(256), 0, e->stream, e->encpart, e->enc_wgs / e->ngrp, 32 * e->Wp,
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(32 * e->Wp)), dim3(256), 0, e->stream, e->encpart, e->encb_parts, 32 * e->Wp,
                            0.5f, e->P, (const float*)nullptr, (float*)nullptr);
         if ((rc = launch_check(e, "enc_reduce"))) return rc;
     }
@@ -614,7 +615,11 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
 #undef PV_K3
         } else {
 #define PV_K3(TR, MD) pvk_dec<N_, TR, MD>
-            if (mode == 1) {  // read-only pass: small LDS footprint, its own (larger) grid
+            if (mode == 0 && e->dec2_wgs) {  // plain training pass: block-column split
+                PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_dec2<N_>, dim3(e->dec2_wgs), dim3(PvDec2<N_>::NW * 64), PvDec2<N_>::lds(),
+                                                      e->stream, aV, amV, avV, aV2, amV2, avV2, acb, amC, avC, gD, e->Xt, e->nblk,
+                                                      (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4));
+            } else if (mode == 1) {  // read-only pass: small LDS footprint, its own (larger) grid
                 PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 0, PV_MODE_TRAIN>), dim3(e->dec_eval_wgs), dim3(256), lds_dec_eval(N_),
                                                       e->stream, aV, amV, avV, aV2, amV2, avV2, acb, amC, avC, gD, e->Xt, e->nblk,
                                                       (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4, agV, agC));
@@ -630,7 +635,8 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
         const int n_dg = mode == 1 ? 0 : 32 * e->Wp;
         // eval: only the recon sums are produced (they live behind the dg block of the exchange buffer)
         hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(n_dg)), dim3(256), 0, e->stream, e->dgpart,
-                           mode == 1 ? e->dec_eval_wgs : e->dec_wgs, n_dg, 1.0f, e->xch1, e->losspart, e->xch1 + 32 * e->Wp);
+                           mode == 1 ? e->dec_eval_wgs : (mode == 0 && e->dec2_wgs) ? e->dec2_wgs : e->dec_wgs, n_dg, 1.0f, e->xch1,
+                           e->losspart, e->xch1 + 32 * e->Wp);
         if ((rc = launch_check(e, "dec_reduce"))) return rc;
     }
     return 0;
@@ -644,8 +650,8 @@ int enc_bwd_launch(pvae_engine* e, int km, bool fuse = false, int next_off = 0, 
     float* nof = nullptr;
     const float* nogw = nullptr;
     const PvBwdOp* noops = nullptr;
-    const int adam_units = adam_ops ? 16 * e->n_bwd_ops : 0;
-    if (adam_units > 4 * e->encb_wgs) return set_err(e, -6, "narrow Adam units exceed the wide encoder backward's waves");
+    // plain training: the narrow layers' dW + Adam units take the first workgroups of the launch (one unit per wave)
+    const int adam_units = adam_ops ? 16 * e->n_bwd_ops : 0, adam_wgs = (adam_units + 3) / 4;
     if (km == PV_MODE_GRAD) {
         if (!e->W1.g && (rc = allocf(e, &e->W1.g, e->W1.n))) return rc;
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_GRAD, 0>), dim3(e->encb_wgs), dim3(256),
@@ -660,14 +666,14 @@ int enc_bwd_launch(pvae_engine* e, int km, bool fuse = false, int next_off = 0, 
                                               (int64_t)0, nor, 0, 0, nof, e->ts4, (const float*)e->W1.g, noops, 0));
         e->W1.swap();
     } else if (fuse) {
-        PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 1>), dim3(e->encb_wgs), dim3(256),
-                                              lds_enc_bwd_fused(N_, e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
+        PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 1>), dim3(e->encb_wgs + adam_wgs), dim3(256),
+                                              lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
                                               e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam,
                                               (const uint8_t*)e->geno, e->row_bytes, (const int*)e->d_rows, next_off, next_n,
                                               e->encpart, e->ts4, nogw, adam_ops, adam_units));
         e->W1.swap();
     } else {
-        PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 0>), dim3(e->encb_wgs), dim3(256),
+        PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 0>), dim3(e->encb_wgs + adam_wgs), dim3(256),
                                               lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
                                               e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam, nog,
                                               (int64_t)0, nor, 0, 0, nof, e->ts4, nogw, adam_ops, adam_units));
@@ -695,9 +701,9 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
     const PvBwdOp* table = km == PV_MODE_GRAD ? e->d_bwd_ops_grad : e->d_bwd_ops;
     if (e->fused_narrow) {
         if ((rc = ensure_narrow_packed(e))) return rc;
-        // plain training: the narrow layers' dW + Adam units ride on the first workgroups of the wide encoder backward
-        // (one unit per wave), unless the SNP shard is so small that its grid has fewer waves than there are units
-        const bool ride = mode == 0 && 16 * e->n_bwd_ops <= 4 * e->encb_wgs;
+        // plain training: the narrow layers' dW + Adam units ride on the launch of the wide encoder backward (its first
+        // workgroups, one unit per wave) instead of an 8 us launch of their own on an otherwise idle chip
+        const bool ride = mode == 0;
         {
         Timer t(e, C_NARROW_BWD);
         const dim3 chain_grid(mode == 1 ? 1 : e->narrow_warm ? 8 * (e->n_bwd_ops + 1) : PVN_WORKERS);
@@ -979,6 +985,12 @@ int pvae_debug_trace(unsigned long long* out, int n) {
 }
 #endif
 
+#ifdef PV_WTRACE
+int pvae_debug_wtrace(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pv_wtrace_buf), n * sizeof(unsigned long long));
+}
+#endif
+
 int pvae_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1092,24 +1104,19 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
         hipDeviceProp_t prop;
         HK(hipGetDeviceProperties(&prop, e->dev));
         const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        int o_enc = 1, o_dec = 1, o_encb = 1;
+        int o_dec = 1, o_encb = 1;
         PV_DISPATCH_NWB(e, {
-            HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_enc, pvk_enc_fwd<N_>, 256, lds_enc_fwd(N_)));
             if (e->ngrp == 1)
                 HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, pvk_dec<N_, 1, PV_MODE_TRAIN>, 256, lds_dec(N_)));
             else if (e->ngrp == 2)
                 HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, (pvk_dec_grp<2, 1, PV_MODE_TRAIN, dec_grp_waves(2)>), 64 * dec_grp_waves(2), lds_dec_grp(2)));
             else
                 HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_dec, (pvk_dec_grp<4, 1, PV_MODE_TRAIN, dec_grp_waves(4)>), 64 * dec_grp_waves(4), lds_dec_grp(4)));
-            if (!getenv("PVAE_NO_FUSE_FWD"))
-                HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_encb, (pvk_enc_bwd<N_, PV_MODE_TRAIN, 1>), 256, lds_enc_bwd_fused(N_, e->Wp)));
-            else
-                HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_encb, (pvk_enc_bwd<N_, PV_MODE_TRAIN, 0>), 256, lds_enc_bwd(e->Wp)));
+            HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_encb, (pvk_enc_bwd<N_, PV_MODE_TRAIN, 1>), 256, lds_enc_bwd(e->Wp)));
         });
         auto envi = [](const char* k, int dflt) { const char* v = getenv(k); return v && *v ? atoi(v) : dflt; };
-        o_enc = envi("PVAE_ENC_OCC", std::min(std::max(o_enc, 1), 2));
         o_dec = envi("PVAE_DEC_OCC", std::max(o_dec, 1));
-        o_encb = envi("PVAE_ENCB_OCC", std::max(o_encb, 1));
+        o_encb = envi("PVAE_ENCB_OCC", std::min(std::max(o_encb, 1), 2));  // 2 workgroups per CU measured best (tools/gpu_occ_sweep.sh)
         // Small shapes (and SNP shards) give a wave only a few subtiles: with the full co-resident grid some waves would
         // stream one subtile more than the others and the last round would run on a partly idle chip (3125 blocks over 2048
         // waves: 2 rounds at 76 %).  Up to 8 rounds the grid is shrunk so that every wave gets the same count (1563 waves
@@ -1120,19 +1127,33 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
             if (rounds <= 1 || rounds > 8) return std::min(units, slots_max);
             return (units + rounds - 1) / rounds;
         };
-        auto enc_grid = [&](int occ) {  // waves of a group share the SNP blocks round-robin; grid is a multiple of ngrp
-            const int64_t per_group = balance(e->nblk, std::max<int64_t>(1, (int64_t)cus * occ * 4 / e->ngrp));
-            const int64_t wgs = (per_group * e->ngrp + 3) / 4;
-            return (int)std::max<int64_t>(1, (wgs + e->ngrp - 1) / e->ngrp) * e->ngrp;
-        };
-        e->enc_wgs = enc_grid(o_enc);
-        e->encb_wgs = enc_grid(o_encb);
+        {   // pvk_enc_bwd: the training pass works in 32 x 32 blocks, wave gw of a unit group on block column gw % NWB of subtile
+            // slots gw / NWB, gw / NWB + nslots, ...: the waves of a group, 4 * workgroups, have to be a multiple of NWB.  The
+            // whole grid -- sweep workgroups plus the ones that carry the narrow layers' Adam units -- is co-resident.
+            const int q = e->NWB == 3 ? 3 : 1;  // workgroups per group in steps of q
+            const int adam_wgs = 4 * (2 * e->D + 2);
+            int64_t per_group = ((int64_t)e->nblk * e->NWB + 3) / 4;  // one block per wave: more workgroups would idle
+            per_group = std::min<int64_t>(per_group, std::max<int64_t>(1, ((int64_t)cus * o_encb - adam_wgs) / e->ngrp));
+            per_group = envi("PVAE_ENCB_WGS", (int)(per_group * e->ngrp)) / e->ngrp;
+            per_group = std::max<int64_t>(q, (per_group + q - 1) / q * q);
+            e->encb_wgs = (int)per_group * e->ngrp;
+            e->encb_parts = (int)(per_group * 4 / e->NWB);
+            e->enc_wgs = e->encb_wgs;  // the stand-alone forward: same decomposition, bit-identical partial tiles
+        }
         if (e->ngrp == 1) e->dec_wgs = (int)((balance(e->nblk, (int64_t)cus * o_dec * 4) + 3) / 4);
         else {  // a workgroup takes dec_grp_waves / ngrp SNP blocks per iteration
             const int bpi = dec_grp_waves(e->ngrp) / e->ngrp;
             e->dec_wgs = (int)balance((e->nblk + bpi - 1) / bpi, (int64_t)cus * o_dec);
         }
         e->dec_wgs = clampi(envi("PVAE_DEC_WGS", e->dec_wgs), 1, (e->nblk + 3) / 4);
+        if (e->ngrp == 1 && !getenv("PVAE_NO_DEC2")) {
+            // pvk_dec2: a workgroup takes BPI = NW / NWB subtiles per iteration; the whole grid is co-resident
+            int o2 = 2;
+            PV_DISPATCH_NWB(e, HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, pvk_dec2<N_>, PvDec2<N_>::NW * 64, PvDec2<N_>::lds())));
+            o2 = envi("PVAE_DEC2_OCC", std::min(std::max(o2, 1), 2));
+            const int bpi = e->NWB == 3 ? 1 : 4 / e->NWB;
+            e->dec2_wgs = clampi(envi("PVAE_DEC2_WGS", cus * o2), 1, (e->nblk + bpi - 1) / bpi);
+        }
         e->dec_eval_wgs = e->dec_wgs;
         if (e->ngrp == 1) {
             int o_eval = 2;
@@ -1141,15 +1162,15 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
             o_eval = envi("PVAE_DECE_OCC", std::min(std::max(o_eval, 1), 4));
             e->dec_eval_wgs = (int)((balance(e->nblk, (int64_t)cus * o_eval * 4) + 3) / 4);
         }
-        e->encb_wgs = clampi(envi("PVAE_ENCB_WGS", e->encb_wgs) / e->ngrp, 1, (e->nblk + 3) / 4) * e->ngrp;
         if (getenv("PVAE_VERBOSE"))
-            fprintf(stderr, "[pvae] CUs %d; blocks/CU enc_fwd %d dec %d enc_bwd %d; grids %d %d %d, dec eval %d\n", cus, o_enc, o_dec, o_encb,
+            fprintf(stderr, "[pvae] CUs %d; blocks/CU dec %d enc_bwd %d; grids enc_fwd %d dec %d enc_bwd %d (+ Adam workgroups), dec eval %d\n", cus, o_dec, o_encb,
                     e->enc_wgs, e->dec_wgs, e->encb_wgs, e->dec_eval_wgs);
     }
-    CK(allocf(e, &e->encpart, (int64_t)std::max(e->enc_wgs, e->encb_wgs) * e->NWB * 1024));
+    e->encpart_floats = (int64_t)e->encb_parts * 32 * e->Wp;
+    CK(allocf(e, &e->encpart, e->encpart_floats));
     e->fuse_fwd = !getenv("PVAE_NO_FUSE_FWD");
-    CK(allocf(e, &e->dgpart, (int64_t)e->dec_wgs * 32 * e->Wp));
-    CK(allocf(e, &e->losspart, (int64_t)std::max(e->dec_wgs, e->dec_eval_wgs)));
+    CK(allocf(e, &e->dgpart, (int64_t)std::max(e->dec_wgs, e->dec2_wgs) * 32 * e->Wp));
+    CK(allocf(e, &e->losspart, (int64_t)std::max(std::max(e->dec_wgs, e->dec2_wgs), e->dec_eval_wgs)));
 
     HK(hipMalloc(&e->st, sizeof(PvStep)));
     PvStep st0{};
@@ -1329,8 +1350,9 @@ int pvae_train_step_noalloc(pvae_engine* e, const int32_t* rows, int32_t n, cons
         return set_err(e, -5, "pvae_train_step_noalloc: SNP-sharded engines exchange through RCCL, which allocates");
     if (e->timing) return set_err(e, -6, "pvae_train_step_noalloc: switch event timing off first (events are created on demand)");
     auto al = [](size_t floats) { return (floats + 63) / 64 * 64; };  // 256-byte steps
-    const size_t n_enc = al((size_t)std::max(e->enc_wgs, e->encb_wgs) * e->NWB * 1024);
-    const size_t n_dg = al((size_t)e->dec_wgs * 32 * e->Wp), n_loss = al((size_t)std::max(e->dec_wgs, e->dec_eval_wgs));
+    const size_t n_enc = al((size_t)e->encpart_floats);
+    const size_t n_dg = al((size_t)std::max(e->dec_wgs, e->dec2_wgs) * 32 * e->Wp);
+    const size_t n_loss = al((size_t)std::max(std::max(e->dec_wgs, e->dec2_wgs), e->dec_eval_wgs));
     const size_t need = (n_enc + n_dg + n_loss) * sizeof(float);
     if (need > PV_SCRATCH_BYTES)
         return set_err(e, -8, "pvae_train_step_noalloc: this model's partial-sum buffers need %zu bytes, the static scratch "

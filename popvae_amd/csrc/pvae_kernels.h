@@ -29,6 +29,14 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// -DPV_WTRACE: per-workgroup timeline of the wide kernels (100 MHz wall clock): [kernel 0 = dec, 1 = enc_bwd][workgroup][point]
+#ifdef PV_WTRACE
+__device__ unsigned long long pv_wtrace_buf[2 * 1024 * 6];  // points 0..3 = times, 4 = HW_ID register, 5 = XCC_ID register
+#define PV_WT(k, pt) do { if (threadIdx.x == 0 && blockIdx.x < 1024) { unsigned long long* p_ = pv_wtrace_buf + ((k) * 1024 + blockIdx.x) * 6; \
+    p_[pt] = wall_clock64(); if ((pt) == 0) { p_[4] = __builtin_amdgcn_s_getreg(63492); p_[5] = __builtin_amdgcn_s_getreg(63508); } } } while (0)
+#else
+#define PV_WT(k, pt) do {} while (0)
+#endif
 #define PV_ROW(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))
 // index of element (row b, column n) of a 32 x 32 result in the [16][64] accumulator-ordered LDS tile: inverse of PV_ROW
 #define PV_TILE_IDX(b, n) (((((b) & 3) + 4 * ((b) >> 3)) << 6) + ((((b) >> 2) & 1) << 5) + (n))
@@ -149,67 +157,63 @@ __global__ __launch_bounds__(256) void pvk_gather_transpose(const uint8_t* __res
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wide encoder forward: partial[b][u] = sum_l code(b,l) * W1[l][u] over this wave's SNP blocks.
-// grid = nwg workgroups of 4 waves; global wave gw owns group grp = gw % ngrp and a contiguous chunk
-// of SNP blocks.  Per-wave partials are written to part[gw][r-major fragment] and reduced in fixed
-// order by pvk_enc_reduce (deterministic split-K).
+// Wide encoder forward: partial[b][u] = sum_l code(b,l) * W1[l][u] over this wave's 32 x 32 blocks.
+// Block-column-major, exactly as the fused forward inside pvk_enc_bwd (pv_enc_bwd_train): the waves of a unit group
+// (grp = blockIdx.x % ngrp) are numbered gw; wave gw owns block column w = gw % NWB of the subtiles slot, slot + nslots, ...
+// (slot = gw / NWB) and writes its 32 x 32 fragment into the partial tile part[slot][32][Wp].  Launched on the same
+// number of workgroups as that pass, both produce bit-identical partial tiles (same products in the same order), which
+// pvk_reduce_parts sums in a fixed order: a step computes the same numbers whichever of the two paths fed it.
 // ---------------------------------------------------------------------------------------------
 template <int NWB>
 __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1, const uint8_t* __restrict__ geno,
                                                    int64_t row_bytes, const int* __restrict__ rows,
                                                    const PvStep* st, int row_offset, int nblk, int ngrp,
                                                    float* __restrict__ part, int ts) {
-    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-    // all 4 waves of a workgroup work on the same group of 128 units (their fragments are summed below);
-    // gridDim.x is a multiple of ngrp
-    const int grp = blockIdx.x % ngrp, slot = (blockIdx.x / ngrp) * 4 + (threadIdx.x >> 6);
-    const int nslots = (gridDim.x / ngrp) * 4;
+    constexpr int WG_UNITS = NWB * 32;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int grp = blockIdx.x % ngrp, gw = (blockIdx.x / ngrp) * 4 + wave;
+    const int slot = gw / NWB, w = gw - slot * NWB;
+    const int nslots = (gridDim.x / ngrp) * 4 / NWB;  // the host sizes the grid so that this divides
     const int nrows = st->nrows;
     const uint8_t* xrow = nullptr;
     if (c < nrows) xrow = geno + (int64_t)rows[row_offset + c] * row_bytes;
 
-    f32x16 acc[NWB];
+    f32x16 acc;
 #pragma unroll
-    for (int w = 0; w < NWB; ++w)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[w][r] = 0.f;
-
-    for (int blk = slot; blk < nblk; blk += nslots) {  // round-robin, see pvk_dec
-        const f32x4* tile = reinterpret_cast<const f32x4*>(W1) + ((int64_t)blk * ngrp + grp) * ts;
-        f32x4 wv[NWB][4];
-#pragma unroll
-        for (int w = 0; w < NWB; ++w)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wv[w][q] = __builtin_nontemporal_load(tile + (w * 4 + q) * 64 + lane);
-        uint64_t xw = 0;
-        if (xrow) xw = *reinterpret_cast<const uint64_t*>(xrow + (int64_t)blk * 8);
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto mma = [&](const f32x4 (&wv)[4], uint64_t xw) {
         xw >>= (8 * h);
         const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float a = pv_code(lo, hi, r);
+        for (int r = 0; r < 16; ++r)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv_code(lo, hi, r), wv[r >> 2][r & 3], acc, 0, 0, 0);
+    };
+    auto request = [&](f32x4 (&wv)[4], uint64_t& xw, int blk_) {
+        const f32x4* tile = reinterpret_cast<const f32x4*>(W1) + ((int64_t)blk_ * ngrp + grp) * ts + w * 256 + lane;
 #pragma unroll
-            for (int w = 0; w < NWB; ++w)
-                acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wv[w][r >> 2][r & 3], acc[w], 0, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q) wv[q] = __builtin_nontemporal_load(tile + q * 64);
+        xw = xrow ? *reinterpret_cast<const uint64_t*>(xrow + (int64_t)blk_ * 8) : 0ull;
+    };
+    int blk = slot;
+    // four blocks (16 KiB per wave) requested before the first is used
+    for (; blk + 3 * nslots < nblk; blk += 4 * nslots) {
+        f32x4 wv[4][4];
+        uint64_t xw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) request(wv[u], xw[u], blk + u * nslots);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mma(wv[u], xw[u]);
     }
-    // workgroup-level fixed-order reduce of the 4 waves' fragments, then one row-major partial per
-    // workgroup: part[wg][b][u]  (b = ROW(r,h), u = w*32 + c)
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][NWB*16][64]
-    const int wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int w = 0; w < NWB; ++w)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[((wave * NWB + w) * 16 + r) * 64 + lane] = acc[w][r];
-    __syncthreads();
-    // part[blockIdx.x / ngrp][b][Wp]: this workgroup fills the columns of its group
-    const int ldp = ngrp * NWB * 32;
-    float* p = part + (int64_t)(blockIdx.x / ngrp) * (32 * ldp) + grp * (NWB * 32);
-    for (int e = threadIdx.x; e < NWB * 1024; e += 256) {
-        const float sum = ((red[e] + red[NWB * 1024 + e]) + red[2 * NWB * 1024 + e]) + red[3 * NWB * 1024 + e];
-        const int w = e >> 10, r = (e >> 6) & 15, ln = e & 63;
-        p[PV_ROW(r, ln >> 5) * ldp + w * 32 + (ln & 31)] = sum;
+    for (; blk < nblk; blk += nslots) {
+        f32x4 wv[4];
+        uint64_t xw;
+        request(wv, xw, blk);
+        mma(wv, xw);
     }
+    const int ldp = ngrp * WG_UNITS;
+    float* p = part + (int64_t)slot * (32 * ldp) + grp * WG_UNITS + w * 32 + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[PV_ROW(r, h) * ldp] = acc[r];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -580,8 +584,10 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
     const float inv_b = st->inv_b, alpha = st->alpha;
     const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
 
+    PV_WT(0, 0);
     for (int i = tid; i < 32 * WP; i += 256) g_s[(i / WP) * LDG + (i % WP)] = g[i];
     __syncthreads();
+    PV_WT(0, 1);
 
     f32x16 dg[NWB];
     float lossacc = 0.f;  // only the batch total enters the loss (popvae.py:423)
@@ -722,6 +728,7 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
     }
     // ---- per-workgroup reductions (fixed order) ----
     __syncthreads();  // everyone done with g_s / wave staging
+    PV_WT(0, 2);
     float* red = smem;  // reuse: [4][NWB*16][64] for dg, then [4][32] loss
     // loss: fixed-order butterfly over the wave, then over the 4 waves
     lossacc += __shfl_xor(lossacc, 1);
@@ -747,6 +754,7 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
             dgpart[(int64_t)blockIdx.x * (32 * WP) + PV_ROW(r, ln >> 5) * WP + w * 32 + (ln & 31)] = s;
         }
     }
+    PV_WT(0, 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -793,7 +801,6 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
     float* vt = smem + 32 * LDG + wave * (2 * 32 * 33);  // [32][33]; also this wave's partial-logit mailbox
     float* dt = vt + 32 * 33;                            // [32][33]
     const int grp = wave % NGRP, bsub = wave / NGRP;
-    const int bgroups = (nblk + BPI - 1) / BPI;
     const int per = (bgroups + gridDim.x - 1) / gridDim.x;
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
@@ -996,6 +1003,259 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wide decoder, training pass for widths up to 128 (one unit group), block-column split: the NWB waves of one SNP block
+// each hold ONE 32-unit block column of the subtile (4 KiB of V | m | v each) instead of one wave holding all of it.
+//   * a wave's whole working set is ~110 registers, so everything it needs is requested a phase ahead: the Adam moments of
+//     this block at the top of the visit (they land during products (1)-(3)), the V block of the NEXT visit as well.  The
+//     one-wave-per-subtile kernel (pvk_dec, 248 registers) issued 2 KiB of moment loads, waited, stored, 16 times per
+//     subtile; a wave took 24-32 us per subtile of which ~9 us were arithmetic (tools/trace_wide.py);
+//   * the unit of work of a workgroup is BPI = NW / NWB subtiles per iteration (1 at width 128): a small problem or SNP
+//     shard spreads evenly over the CUs;
+//   * the partial logits of the NWB waves meet in LDS (the wave's V^T staging tile doubles as its mailbox) and every wave
+//     sums them in block-column order, so all hold bit-identical logits; the sigmoid / BCE / dlogits arithmetic is then
+//     done by each of them (16 values per lane), which is cheaper than a second exchange;
+//   * each wave owns a block column of dg: the workgroup's partial tile needs no cross-wave sum when BPI == 1.
+// Waves of ONE SNP block meet at two LDS counters that only grow (pv_block_sync).  LDS: g tile + per wave 2 x [32][33].
+// ---------------------------------------------------------------------------------------------
+template <int NWB>
+struct PvDec2 {
+    static constexpr int NW = NWB == 3 ? 3 : 4;  // waves per workgroup
+    static constexpr int BPI = NW / NWB;         // SNP blocks per workgroup iteration
+    static constexpr int WP = NWB * 32, LDG = WP + 1;
+    static constexpr size_t lds() { return (size_t)(32 * LDG + NW * 2 * 32 * 33) * 4; }
+};
+template <int NWB>
+__global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float* __restrict__ V, const float* __restrict__ mV,
+                                                                    const float* __restrict__ vV, float* __restrict__ V2,
+                                                                    float* __restrict__ mV2, float* __restrict__ vV2,
+                                                                    float* __restrict__ cb, float* __restrict__ mC,
+                                                                    float* __restrict__ vC, const float* __restrict__ g,
+                                                                    const uint64_t* __restrict__ Xt, int nblk, int L,
+                                                                    const PvStep* st, PvAdam adam, float* __restrict__ dgpart,
+                                                                    float* __restrict__ losspart, int ts) {
+    using G = PvDec2<NWB>;
+    constexpr int NW = G::NW, BPI = G::BPI, WP = G::WP, LDG = G::LDG;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* g_s = smem;  // [32][LDG]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, h = lane >> 5;
+    float* vt = smem + 32 * LDG + wave * (2 * 32 * 33);  // [32][33]; also this wave's partial-logit mailbox ([4][64][4])
+    float* dt = vt + 32 * 33;                            // [32][33]
+    const int bsub = wave / NWB, w = wave - bsub * NWB;
+    const float* mb0 = smem + 32 * LDG + (bsub * NWB) * (2 * 32 * 33);  // mailbox of block column 0 of this SNP block
+    const int nrows = st->nrows;
+    const float inv_b = st->inv_b, alpha = st->alpha;
+    __shared__ int blk_sync[BPI][2];  // [0] partial logits posted, [1] partial logits read (both only ever grow)
+    if (tid < 2 * BPI) blk_sync[tid >> 1][tid & 1] = 0;
+    bool sync_ok = true;
+    int nsync = 0;
+    PV_WT(0, 0);
+
+    // visit `it` of this wave: SNP block (it * gridDim.x + blockIdx.x) * BPI + bsub, block column w
+    auto block_of = [&](int it) { return (it * (int)gridDim.x + (int)blockIdx.x) * BPI + bsub; };
+    auto tile = [&](int blk_) { return (int64_t)blk_ * ts + w * 256 + lane; };
+    f32x4 vv[4], vn[4];
+    uint64_t xw = 0, xw_n = 0;
+    float bias = 0.f, bias_n = 0.f;
+    int blk = block_of(0);
+    if (blk < nblk) {  // the first block travels while g is staged
+        const f32x4* tV = reinterpret_cast<const f32x4*>(V) + tile(blk);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vv[q] = __builtin_nontemporal_load(tV + q * 64);
+        xw = Xt[blk * 32 + c];
+        bias = cb[blk * 32 + c];
+    }
+    for (int i = tid; i < 32 * WP; i += NW * 64) g_s[(i / WP) * LDG + (i % WP)] = g[i];
+    __syncthreads();
+    PV_WT(0, 1);
+    // this wave's 32 units of g, as the A operands of products (1) and (4): the same for every visit
+    float g1[16], g4[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        g1[r] = g_s[c * LDG + w * 32 + PV_ROW(r, h)];    // A[i=b][k=unit]
+        g4[r] = g_s[PV_ROW(r, h) * LDG + w * 32 + c];    // A[i=unit_loc][k=b]
+    }
+
+    f32x16 dg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dg[r] = 0.f;
+    float lossacc = 0.f;  // only the batch total enters the loss (popvae.py:423)
+
+    for (int it = 0; blk < nblk; ++it) {
+        const int nb = block_of(it + 1) < nblk ? block_of(it + 1) : blk;  // past the end: a harmless re-read
+        const int l = blk * 32 + c;
+        const bool lvalid = l < L;
+        // requests of this visit: the genotype / bias words and V of the next visit, the Adam moments of this block.  The
+        // bias word goes FIRST: loads return in order, so it has landed before product (1) of the next visit can start,
+        // i.e. before that visit's sync points, behind which block column 0 rewrites the bias in place.
+        const int64_t tb = tile(blk);
+        f32x4 mq[4], vq[4];
+        float cm = 0.f, cv = 0.f;
+        {
+            bias_n = cb[nb * 32 + c];
+            xw_n = Xt[nb * 32 + c];
+            if (w == 0 && h == 0 && lvalid) {
+                cm = mC[l];
+                cv = vC[l];
+            }
+            const f32x4* tM = reinterpret_cast<const f32x4*>(mV) + tb;
+            const f32x4* tVv = reinterpret_cast<const f32x4*>(vV) + tb;
+            const f32x4* tVn = reinterpret_cast<const f32x4*>(V) + tile(nb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vn[q] = __builtin_nontemporal_load(tVn + q * 64);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                mq[q] = __builtin_nontemporal_load(tM + q * 64);
+                vq[q] = __builtin_nontemporal_load(tVv + q * 64);
+            }
+        }
+        const uint64_t xs = xw >> (8 * h);
+        const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
+
+        // (1) logits a[b][l] over this wave's 32 units: M = b, N = l, K = unit.  A = g[b][unit], B = V fragment register.
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[r], vv[r >> 2][r & 3], a, 0, 0, 0);
+        }
+        if (NWB > 1) {
+            // the NWB waves of this SNP block meet; the other blocks of the workgroup run on
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 t4 = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+                reinterpret_cast<f32x4*>(vt)[q * 64 + lane] = t4;
+            }
+            ++nsync;
+            sync_ok &= pv_block_sync(&blk_sync[bsub][0], NWB * nsync, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 sum = reinterpret_cast<const f32x4*>(mb0)[q * 64 + lane];
+#pragma unroll
+                for (int w2 = 1; w2 < NWB; ++w2) sum += reinterpret_cast<const f32x4*>(mb0 + w2 * (2 * 32 * 33))[q * 64 + lane];
+                a[4 * q] = sum[0]; a[4 * q + 1] = sum[1]; a[4 * q + 2] = sum[2]; a[4 * q + 3] = sum[3];
+            }
+            // mailboxes double as the V^T staging tiles of product (3): nobody overwrites one before all have read it
+            sync_ok &= pv_block_sync(&blk_sync[bsub][1], NWB * nsync, lane);
+        }
+        // (2) sigmoid / BCE-from-logits / dlogits ; reg r <-> sample b = ROW(r,h), lane <-> SNP l (every wave of the block
+        //     computes the same values)
+        float dbias = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = PV_ROW(r, h);
+            const float x = 0.5f * pv_code(lo, hi, r);
+            const float z = a[r] + bias;
+            const float e = __expf(-fabsf(z));                 // exp(-|z|)
+            const float bce = fmaxf(z, 0.f) - z * x + __logf(1.f + e);
+            const float inv = __builtin_amdgcn_rcpf(1.f + e);
+            const float p = z >= 0.f ? inv : e * inv;            // sigmoid(z)
+            const bool ok = lvalid && (b < nrows);
+            lossacc += (ok && w == 0) ? bce : 0.f;
+            const float d = ok ? (p - x) * inv_b : 0.f;
+            a[r] = d;
+            dbias += d;
+        }
+        // bias: sum over the 32 samples = 16 regs + the other half-wave; block column 0 updates it
+        dbias += __shfl_xor(dbias, 32);
+        if (w == 0 && h == 0 && lvalid) {
+            float w_ = bias;
+            pv_adam(w_, cm, cv, dbias, alpha, adam);
+            cb[l] = w_;
+            mC[l] = cm;
+            vC[l] = cv;
+        }
+        // (3) dg[b][unit] += sum_l da[b][l] * V[unit][l] : M = b, N = unit, K = l.  A needs da^T, B needs V^T (unit on the
+        //     lane): both staged through this wave's LDS tiles.
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dt[PV_ROW(r, h) * 33 + c] = a[r];                 // [b][l_loc]
+            vt[PV_ROW(r, h) * 33 + c] = vv[r >> 2][r & 3];    // [unit_loc][l_loc]
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float av = dt[c * 33 + PV_ROW(r, h)];  // A[i=b][k=l]
+            const float bv = vt[c * 33 + PV_ROW(r, h)];  // B[k=l][j=unit_loc]
+            dg = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, dg, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // (4) dV[unit][l] = sum_b g[b][unit] * da[b][l] : M = unit, N = l, K = b ; then Adam on the block
+        f32x16 dv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dv[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dv = __builtin_amdgcn_mfma_f32_32x32x2f32(g4[r], a[r], dv, 0, 0, 0);
+        }
+        f32x4* oV = reinterpret_cast<f32x4*>(V2) + tb;
+        f32x4* oM = reinterpret_cast<f32x4*>(mV2) + tb;
+        f32x4* oVv = reinterpret_cast<f32x4*>(vV2) + tb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 wq = vv[q], m4 = mq[q], v4 = vq[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float w_ = wq[e], m_ = m4[e], v_ = v4[e];
+                pv_adam(w_, m_, v_, dv[q * 4 + e], alpha, adam);
+                wq[e] = w_;
+                m4[e] = m_;
+                v4[e] = v_;
+            }
+            __builtin_nontemporal_store(wq, oV + q * 64);
+            __builtin_nontemporal_store(m4, oM + q * 64);
+            __builtin_nontemporal_store(v4, oVv + q * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vv[q] = vn[q];
+        xw = xw_n;
+        bias = bias_n;
+        blk = block_of(it + 1);
+    }
+    // ---- per-workgroup reductions (fixed order) ----
+    __syncthreads();  // everyone done with g_s / the staging tiles
+    PV_WT(0, 2);
+    float* red = smem;  // [NW][16][64] for dg when BPI > 1, then [NW] loss
+    lossacc += __shfl_xor(lossacc, 1);
+    lossacc += __shfl_xor(lossacc, 2);
+    lossacc += __shfl_xor(lossacc, 4);
+    lossacc += __shfl_xor(lossacc, 8);
+    lossacc += __shfl_xor(lossacc, 16);
+    lossacc += __shfl_xor(lossacc, 32);
+    if (!sync_ok) lossacc = __builtin_nanf("");  // a sync point gave up: make the step loudly wrong
+    float* lred = red + NW * 1024;
+    if (lane == 0) lred[wave] = lossacc;
+    if (BPI > 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = dg[r];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float sacc = 0.f;
+        for (int w2 = 0; w2 < NW; ++w2) sacc += lred[w2];
+        losspart[blockIdx.x] = sacc;
+    }
+    float* dgp = dgpart + (int64_t)blockIdx.x * (32 * WP);
+    if (BPI > 1) {
+        for (int e = tid; e < NWB * 1024; e += NW * 64) {
+            const int wq = e >> 10, f = e & 1023;  // block column, fragment element
+            float sum = red[wq * 1024 + f];
+#pragma unroll
+            for (int b2 = 1; b2 < BPI; ++b2) sum += red[(b2 * NWB + wq) * 1024 + f];
+            const int r = f >> 6, ln = f & 63;
+            dgp[PV_ROW(r, ln >> 5) * WP + wq * 32 + (ln & 31)] = sum;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dgp[PV_ROW(r, h) * WP + w * 32 + c] = dg[r];
+    }
+    PV_WT(0, 3);
+}
+
+// ---------------------------------------------------------------------------------------------
 // decoder.predict (scripts/popvae_decoder_tests_HGDP.py:156): probs[b][l] = sigmoid(g_D[b] . V[:, l] + c[l]) for
 // b < nrows.  One wave per SNP block, looping over the unit groups; read-only pass over V (HBM-bound,
 // 4 B per wide parameter + 4 B per output).
@@ -1065,17 +1325,148 @@ __global__ void pvk_loss_final(const float* __restrict__ recon, const float* __r
 // Wide encoder backward + Adam: dW1[l][u] = 0.5 * sum_b code(b,l) * dpre1[b][u]; M = l, N = u, K = b.
 // One wave per subtile; dpre1 staged once per workgroup in LDS.
 // ---------------------------------------------------------------------------------------------
-// FUSE = 1: the freshly updated tile, still in registers, is also multiplied with the NEXT
-// batch's genotype codes -- the next step's first-layer forward (pvk_enc_fwd) rides along, which saves one
-// full read of W1 (4 of the 52 bytes per wide parameter and step).  Partials go to fpart[workgroup][32][Wp]
-// exactly as pvk_enc_fwd writes them.
-// ADAM_UNITS > 0 (training, fused narrow stack): the first ADAM_UNITS / 4 workgroups first do one unit each per wave of
-// the narrow layers' weight-gradient + Adam work (pvn_adam_unit in pvae_narrow.h; independent of everything this kernel
-// touches), which otherwise is an 8 us launch of 208 single-wave workgroups on an otherwise idle chip.
+// FUSE = 1 (plain training pass only): the freshly updated block, still in registers, is also multiplied with the NEXT
+// batch's genotype codes -- the next step's first-layer forward (pvk_enc_fwd) rides along, which saves one full read of W1
+// (4 of the 52 bytes per wide parameter and step).  Partials go to fpart[slot][32][Wp], summed by pvk_reduce_parts.
 struct PvBwdOp;
 template <int MODE>
 __device__ __forceinline__ void pvn_adam_unit(const PvBwdOp* __restrict__ ops, int bx, int by, int lane_,
                                               const PvStep* __restrict__ st, PvAdam adam);
+// Training pass of pvk_enc_bwd (MODE_TRAIN), block-column-major: the waves of a unit group are numbered gw = 0, 1, ...;
+// wave gw owns block column w = gw % NWB (32 units) of the subtiles slot, slot + nslots, ... (slot = gw / NWB), so
+//   * the unit of work is a 32 x 32 block (12 KiB of W | m | v per wave) instead of a whole subtile: a workgroup's share of a
+//     small problem or SNP shard is even to within one block per wave.  Per-CU evenness is what counts: a CU moves about the
+//     same bytes per microsecond with 4 or 8 resident waves, and with subtile-sized units 100 k SNPs left some CUs twice the
+//     work of others (per-workgroup timeline, tools/trace_wide.py: the kernel ended 25 us after its median workgroup);
+//   * the fused forward needs ONE 32 x 32 accumulator per wave instead of NWB of them (48 registers less at width 128), and the
+//     waves' forward fragments are disjoint blocks of the partial tile fpart[slot][32][Wp]: no cross-wave reduction;
+//   * the sweep is software-pipelined one block deep: the next block (and the genotype words that go with it) is requested
+//     before the current one is touched, so a wave always has 12 KiB of loads in flight and never waits for a request it has
+//     just issued; waits are for the OLDER block only (gfx9 counts loads and stores on one in-order counter).
+// The narrow layers' weight-gradient + Adam units (adam_units > 0) take the first ceil(adam_units / 4) workgroups of the
+// launch, one unit per wave, and exit: carried by sweep waves they delayed those by 10-30 us (their dependent loads crawl
+// while the chip streams), which was the tail of the kernel at small shapes.
+template <int NWB, int FUSE>
+__device__ __forceinline__ void pv_enc_bwd_train(const float* __restrict__ W1, const float* __restrict__ mW,
+                                                 const float* __restrict__ vW, float* __restrict__ W1o, float* __restrict__ mWo,
+                                                 float* __restrict__ vWo, const float* __restrict__ dpre, int ldp,
+                                                 const uint64_t* __restrict__ Xt, int nblk, int ngrp, const PvStep* st, PvAdam adam,
+                                                 const uint8_t* __restrict__ geno, int64_t row_bytes, const int* __restrict__ rows,
+                                                 int next_off, int next_n, float* __restrict__ fpart, int ts,
+                                                 const PvBwdOp* __restrict__ adam_ops, int adam_units, float* smem) {
+    constexpr int WG_UNITS = NWB * 32;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, h = lane >> 5;
+    int bx = blockIdx.x, nwg = gridDim.x;
+    if (adam_ops) {
+        const int awgs = (adam_units + 3) >> 2;
+        if (bx < awgs) {
+            const int unit = bx * 4 + wave;
+            if (unit < adam_units) pvn_adam_unit<PV_MODE_TRAIN>(adam_ops, unit & 15, unit >> 4, lane, st, adam);
+            return;
+        }
+        bx -= awgs;
+        nwg -= awgs;
+    }
+    // (all wave-uniform: the tile addresses live in SGPRs and a lane only holds its 16-byte offset)
+    const int grp = bx % ngrp, gw = (bx / ngrp) * 4 + wave;
+    const int slot = gw / NWB, w = gw - slot * NWB;
+    const int nslots = (nwg / ngrp) * 4 / NWB;  // the host sizes the grid so that this divides
+    const float alpha = st->alpha;
+    struct Block { f32x4 w[4], m[4], v[4]; };
+    auto request = [&](Block& bk, int blk_) {
+        const int64_t o = ((int64_t)blk_ * ngrp + grp) * ts + w * 256 + lane;
+        const f32x4* tW = reinterpret_cast<const f32x4*>(W1) + o;
+        const f32x4* tM = reinterpret_cast<const f32x4*>(mW) + o;
+        const f32x4* tV = reinterpret_cast<const f32x4*>(vW) + o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bk.w[q] = __builtin_nontemporal_load(tW + q * 64);
+            bk.m[q] = __builtin_nontemporal_load(tM + q * 64);
+            bk.v[q] = __builtin_nontemporal_load(tV + q * 64);
+        }
+    };
+    const uint8_t* nrow = nullptr;  // FUSE: lane c's sample of the next batch
+    if (FUSE && c < next_n) nrow = geno + (int64_t)rows[next_off + c] * row_bytes;
+    auto words = [&](int blk_, uint64_t& xw_, uint64_t& xn_) {
+        xw_ = Xt[blk_ * 32 + c];
+        if (FUSE) xn_ = nrow ? *reinterpret_cast<const uint64_t*>(nrow + (int64_t)blk_ * 8) : 0ull;
+    };
+    Block bk[2];
+    uint64_t xw = 0, xn = 0;
+    int blk = slot;
+    if (blk < nblk) {  // the first block travels while dpre is staged
+        request(bk[0], blk);
+        words(blk, xw, xn);
+    }
+    for (int i = tid; i < 32 * ldp; i += 256) {
+        const int b = i / ldp, u = i % ldp;
+        smem[((u / WG_UNITS) * 32 + b) * WG_UNITS + (u % WG_UNITS)] = dpre[i];
+    }
+    __syncthreads();
+    PV_WT(1, 1);
+    const float* dp = smem + grp * 32 * WG_UNITS + w * 32;
+    f32x16 facc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) facc[r] = 0.f;
+    auto block = [&](Block& cur, Block& nxt) {
+        const int nb = blk + nslots < nblk ? blk + nslots : blk;  // past the end: a harmless re-read of this block
+        request(nxt, nb);
+        uint64_t xw2 = 0, xn2 = 0;
+        words(nb, xw2, xn2);
+        const uint64_t xs = xw >> (8 * h), ns = xn >> (8 * h);
+        const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32), nlo = (uint32_t)ns, nhi = (uint32_t)(ns >> 32);
+        const int64_t o = ((int64_t)blk * ngrp + grp) * ts + w * 256 + lane;
+        f32x4* oW = reinterpret_cast<f32x4*>(W1o) + o;
+        f32x4* oM = reinterpret_cast<f32x4*>(mWo) + o;
+        f32x4* oV = reinterpret_cast<f32x4*>(vWo) + o;
+        f32x16 dw;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bv = dp[PV_ROW(r, h) * WG_UNITS + c];  // B[k=b][j=unit]
+            dw = __builtin_amdgcn_mfma_f32_32x32x2f32(pv_code(lo, hi, r), bv, dw, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 wq = cur.w[q], mq = cur.m[q], vq = cur.v[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float w_ = wq[e], m_ = mq[e], v_ = vq[e];
+                pv_adam(w_, m_, v_, 0.5f * dw[q * 4 + e], alpha, adam);
+                wq[e] = w_;
+                mq[e] = m_;
+                vq[e] = v_;
+            }
+            __builtin_nontemporal_store(wq, oW + q * 64);
+            __builtin_nontemporal_store(mq, oM + q * 64);
+            __builtin_nontemporal_store(vq, oV + q * 64);
+            if (FUSE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    facc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv_code(nlo, nhi, q * 4 + e), wq[e], facc, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the next block's requests stay ahead of this block's work, one block deep
+        xw = xw2;
+        xn = xn2;
+        blk += nslots;
+    };
+    while (blk < nblk) {
+        block(bk[0], bk[1]);
+        if (!(blk < nblk)) break;
+        block(bk[1], bk[0]);
+    }
+    PV_WT(1, 2);
+    if (FUSE) {
+        // this wave's block of the partial tile fpart[slot][32][Wp] (waves without work contribute their zeros)
+        const int ldf = ngrp * WG_UNITS;
+        float* p = fpart + (int64_t)slot * (32 * ldf) + grp * WG_UNITS + w * 32 + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[PV_ROW(r, h) * ldf] = facc[r];
+    }
+}
+
 template <int NWB, int MODE, int FUSE>
 __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ W1, const float* __restrict__ mW,
                                                    const float* __restrict__ vW, float* __restrict__ W1o,
@@ -1089,14 +1480,18 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
     constexpr int WG_UNITS = NWB * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [ngrp][32][WG_UNITS]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
-    if (MODE == PV_MODE_TRAIN && adam_ops) {
-        const int unit = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
-        if (unit < adam_units) pvn_adam_unit<PV_MODE_TRAIN>(adam_ops, unit & 15, unit >> 4, lane, st, adam);
+    PV_WT(1, 0);
+    if constexpr (MODE == PV_MODE_TRAIN) {
+        pv_enc_bwd_train<NWB, FUSE>(W1, mW, vW, W1o, mWo, vWo, dpre, ldp, Xt, nblk, ngrp, st, adam, geno, row_bytes, rows, next_off,
+                                    next_n, fpart, ts, adam_ops, adam_units, smem);
+        PV_WT(1, 3);
+        return;
     }
-    // a workgroup stays on ONE unit group (grp = blockIdx.x % ngrp; gridDim.x is a multiple of ngrp): its waves'
-    // forward fragments (FUSE) can then be summed, and neighbouring workgroups still sweep one window of HBM
+    // Gradient dump (MODE_GRAD) and Adam on this pass + the dump (MODE_TRAIN_ACC): tiles of a batch above 32 rows.  One
+    // wave per subtile, round-robin; a workgroup stays on one unit group (gridDim.x is a multiple of ngrp).
+    static_assert(MODE == PV_MODE_TRAIN || FUSE == 0, "the fused forward rides on the plain training pass only");
     const int grp = blockIdx.x % ngrp;
-    const int slot = (blockIdx.x / ngrp) * 4 + wave, nslots = (gridDim.x / ngrp) * 4;
+    const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / ngrp) * 4 + wave), nslots = (gridDim.x / ngrp) * 4;
     const float alpha = st->alpha;
     const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
     for (int i = tid; i < 32 * ldp; i += 256) {
@@ -1104,24 +1499,8 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
         smem[((u / WG_UNITS) * 32 + b) * WG_UNITS + (u % WG_UNITS)] = dpre[i];
     }
     __syncthreads();
-    const uint8_t* nrow = nullptr;  // FUSE: lane c's sample of the next batch
-    f32x16 facc[NWB];
-    if (FUSE) {
-        if (c < next_n) nrow = geno + (int64_t)rows[next_off + c] * row_bytes;
-#pragma unroll
-        for (int w = 0; w < NWB; ++w)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) facc[w][r] = 0.f;
-    }
-    for (int blk = slot; blk < nblk; blk += nslots) {  // round-robin, see pvk_dec
+    for (int blk = slot; blk < nblk; blk += nslots) {
         const int64_t t = (int64_t)blk * ngrp + grp;
-        uint32_t nlo = 0, nhi = 0;
-        if (FUSE) {
-            uint64_t xn = nrow ? *reinterpret_cast<const uint64_t*>(nrow + (int64_t)blk * 8) : 0ull;
-            xn >>= (8 * h);
-            nlo = (uint32_t)xn;
-            nhi = (uint32_t)(xn >> 32);
-        }
         const float* dp = smem + grp * 32 * WG_UNITS;
         uint64_t xw = Xt[blk * 32 + c] >> (8 * h);
         const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
@@ -1154,12 +1533,11 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
                 } else {
                     f32x4 wq = __builtin_nontemporal_load(tW + off), mq = __builtin_nontemporal_load(tM + off),
                           vq = __builtin_nontemporal_load(tV + off);
-                    f32x4 ga = {0.f, 0.f, 0.f, 0.f};
-                    if (MODE == PV_MODE_TRAIN_ACC) ga = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gW) + t * (NWB * 256) + off);
+                    const f32x4 ga = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gW) + t * (NWB * 256) + off);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float w_ = wq[e], m_ = mq[e], v_ = vq[e];
-                        pv_adam(w_, m_, v_, MODE == PV_MODE_TRAIN_ACC ? 0.5f * dw[q * 4 + e] + ga[e] : 0.5f * dw[q * 4 + e], alpha, adam);
+                        pv_adam(w_, m_, v_, 0.5f * dw[q * 4 + e] + ga[e], alpha, adam);
                         wq[e] = w_;
                         mq[e] = m_;
                         vq[e] = v_;
@@ -1167,32 +1545,11 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
                     __builtin_nontemporal_store(wq, oW + off);
                     __builtin_nontemporal_store(mq, oM + off);
                     __builtin_nontemporal_store(vq, oV + off);
-                    if (FUSE) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            facc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv_code(nlo, nhi, q * 4 + e), wq[e], facc[w], 0, 0, 0);
-                    }
                 }
             }
         }
     }
-    if (FUSE) {
-        // fixed-order reduce of the 4 waves' forward fragments (same as pvk_enc_fwd's epilogue)
-        __syncthreads();  // dpre staging is dead
-        float* red = smem;  // [4][NWB*16][64]
-#pragma unroll
-        for (int w = 0; w < NWB; ++w)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[((wave * NWB + w) * 16 + r) * 64 + lane] = facc[w][r];
-        __syncthreads();
-        const int ldf = ngrp * NWB * 32;
-        float* p = fpart + (int64_t)(blockIdx.x / ngrp) * (32 * ldf) + grp * (NWB * 32);
-        for (int e = tid; e < NWB * 1024; e += 256) {
-            const float sum = ((red[e] + red[NWB * 1024 + e]) + red[2 * NWB * 1024 + e]) + red[3 * NWB * 1024 + e];
-            const int w = e >> 10, r = (e >> 6) & 15, ln = e & 63;
-            p[PV_ROW(r, ln >> 5) * ldf + w * 32 + (ln & 31)] = sum;
-        }
-    }
+    PV_WT(1, 3);
 }
 
 // ---------------------------------------------------------------------------------------------

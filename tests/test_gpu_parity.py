@@ -372,5 +372,7 @@ def test_staged_step_with_promised_next_batch():
     la, wa = run(False)
     lb, wb = run(True)
     assert np.allclose(la, lb, rtol=1e-6), (la, lb)
+    # the two forward paths group the split-K partial sums differently (rounding-level differences in the activations);
+    # Adam turns a gradient difference d on a near-zero gradient into lr * d / eps of weight difference
     for i, (a, b) in enumerate(zip(wa, wb)):
-        assert np.abs(a - b).max() <= 1e-6, (i, np.abs(a - b).max())
+        assert np.abs(a - b).max() <= 1e-5, (i, np.abs(a - b).max())
