@@ -801,6 +801,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
     float* vt = smem + 32 * LDG + wave * (2 * 32 * 33);  // [32][33]; also this wave's partial-logit mailbox
     float* dt = vt + 32 * 33;                            // [32][33]
     const int grp = wave % NGRP, bsub = wave / NGRP;
+    const int bgroups = (nblk + BPI - 1) / BPI;
     const int per = (bgroups + gridDim.x - 1) / gridDim.x;
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
