@@ -38,4 +38,10 @@ for k, name in enumerate(("dec", "enc_bwd")):
         ends = [t[i, 3] for v in per_cu.values() if len(v) == cnt for i in v]
         print(f"  CUs holding {cnt} workgroup(s): {sum(1 for v in per_cu.values() if len(v) == cnt)}; their workgroups end at median {np.median(ends):.1f}, max {np.max(ends):.1f} us")
     xs = sorted(set((cu >> 8).tolist()))
+    print("  median / max end per XCD:", [(round(float(np.median(t[(cu >> 8) == x, 3])), 1), round(float(t[(cu >> 8) == x, 3].max()), 1)) for x in xs])
+    nq = 8
+    edges = np.linspace(0, len(t), nq + 1).astype(int)
+    print("  median end per eighth of the workgroup indices:", [round(float(np.median(t[edges[i]:edges[i + 1], 3])), 1) for i in range(nq)])
+    se = (cu >> 5) & 7
+    print("  median end per shader engine id:", {int(x): round(float(np.median(t[se == x, 3])), 1) for x in sorted(set(se.tolist()))})
     print("  workgroups per XCD:", [int(np.sum((cu >> 8) == x)) for x in xs], " first 12 workgroups' (xcc, cu):", [(int(c_ >> 8), int(c_ & 255)) for c_ in cu[:12]])
