@@ -430,7 +430,7 @@ int run_dense_bwd(pvae_engine* e, Dense& d, const float* Y, const float* dY, flo
 }
 
 // stage A: batch gather/transposes + partial wide-encoder sums -> P (pre-bias, this rank's SNPs only)
-int stage_a(pvae_engine* e, int row_offset, bool need_xt, bool fwd_done = false) {
+int stage_a(pvae_engine* e, int row_offset, bool need_xt, bool fwd_done = false, bool reduced = false) {
     int rc;
     if (!e->geno) return set_err(e, -3, "no genotypes loaded (pvae_load_genotypes)");
     if (need_xt) {
@@ -440,7 +440,9 @@ int stage_a(pvae_engine* e, int row_offset, bool need_xt, bool fwd_done = false)
                            e->d_rows, e->st, row_offset, e->nblk, e->Xt);
         if ((rc = launch_check(e, "gather_transpose"))) return rc;
     }
-    if (fwd_done) {
+    if (fwd_done && reduced) {
+        // ... and the step-head launch (pvk_step_begin_gather) has summed them into P
+    } else if (fwd_done) {
         // the previous step's pvk_enc_bwd<.., FUSE = 1> already left this batch's partial sums in encpart
         hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(32 * e->Wp)), dim3(256), 0, e->stream, e->encpart, e->encb_parts,
                            32 * e->Wp, 0.5f, e->P, (const float*)nullptr, (float*)nullptr);
@@ -804,7 +806,7 @@ int check_rows(pvae_engine* e, const int32_t* rows, int64_t n) {
 }
 
 // upload rows/eps for a single batch and run pvk_step_begin
-constexpr size_t kSlotBytes = 32 * sizeof(int) + 32 * 16 * sizeof(float);
+constexpr size_t kSlotBytes = 32 * sizeof(int) + 32 * 64 * sizeof(float);  // 32 rows + their noise at latent_dim <= 64
 int begin_batch(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, bool train) {
     int rc;
     if (n <= 0 || n > e->cfg.batch_size) return set_err(e, -2, "batch of %d rows (batch_size %d)", n, e->cfg.batch_size);
@@ -1015,7 +1017,8 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     if (cfg->batch_size < 1 || cfg->batch_size > 65536)
         return bail(set_err(e, -2, "batch_size %d unsupported (1..65536)", cfg->batch_size));
     if (cfg->width > 512) return bail(set_err(e, -2, "width %d unsupported: this build handles widths up to 512", cfg->width));
-    if (cfg->latent_dim > 16) return bail(set_err(e, -2, "latent_dim %d unsupported (max 16)", cfg->latent_dim));
+    // 2 * latent_dim heads are one layer of at most 128 outputs (the narrow chain's widest tile)
+    if (cfg->latent_dim > 64) return bail(set_err(e, -2, "latent_dim %d unsupported (max 64)", cfg->latent_dim));
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return bail(set_err(e, -20, "no HIP device visible: popvae_amd has no CPU fallback"));
@@ -1419,12 +1422,15 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
                 if (s + 1 < st_tr) { next_off = (s + 1) * B; next_n = std::min(B, n_train - next_off); fuse = true; }
                 else if (st_va > 0) { next_off = n_train; next_n = std::min(B, (int)n_val); fuse = true; }
             }
-            // per-step scalars + noise + batch gather in one launch
-            hipLaunchKernelGGL(pvk_step_begin_gather, dim3(((e->nblk + 1) / 2 + 3) / 4 + 1), dim3(256), 0, e->stream, e->st,
+            // per-step scalars + noise + batch gather (+ the sum of the first-layer partial tiles the previous step's wide
+            // encoder backward left behind) in one launch
+            const int nred = fwd_done ? PV_REDUCE_GRID(32 * e->Wp) : 0;
+            hipLaunchKernelGGL(pvk_step_begin_gather, dim3(nred + ((e->nblk + 1) / 2 + 3) / 4 + 1), dim3(256), 0, e->stream, e->st,
                                (const int*)e->d_ntotal, B, s, phase == 0 ? 1 : 0, e->adam.b1, e->adam.b2, e->eps, 32 * e->K,
-                               e->cfg.seed, e->d_counter, e->geno, e->row_bytes, (const int*)e->d_rows, base + s * B, e->nblk, e->Xt);
+                               e->cfg.seed, e->d_counter, e->geno, e->row_bytes, (const int*)e->d_rows, base + s * B, e->nblk, e->Xt,
+                               nred, (const float*)e->encpart, e->encb_parts, 32 * e->Wp, e->P);
             if ((rc = launch_check(e, "step_begin/gen_eps/gather"))) return rc;
-            if ((rc = stage_a(e, base + s * B, false, fwd_done))) return rc;
+            if ((rc = stage_a(e, base + s * B, false, fwd_done, fwd_done))) return rc;
             if ((rc = shard_allreduce(e, 0))) return rc;
             if ((rc = stage_b(e, phase == 0 ? 0 : 1))) return rc;
             if ((rc = shard_allreduce(e, 1))) return rc;

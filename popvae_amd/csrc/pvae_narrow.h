@@ -287,26 +287,18 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
             // cur holds the heads output: cols [0,K) = z_mean, [K,2K) = z_log_var; nxt gets z (padded to Kz)
             if (tid < PVN_ROWS) {
                 const int lr = tid, b = rb + tid;  // row in LDS, row of the batch
-                float mu[16], sv[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    mu[k] = k < K ? cur[lr * PVN_LD + k] : 0.f;
-                    sv[k] = k < K ? cur[lr * PVN_LD + K + k] : 0.f;
-                }
                 float acc = 0.f;
-                for (int k = 0; k < Kz; ++k) {
-                    nxt[lr * PVN_LD + k] = 0.f;
-                    z_out[b * Kz + k] = 0.f;
-                }
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
+                for (int k = 0; k < Kz; ++k) {  // (cur and nxt are different buffers)
+                    float zz = 0.f;
                     if (k < K) {
-                        const float es = expf(sv[k]);
-                        const float zz = mu[k] + es * eps[b * K + k];  // exp(s), not exp(s/2): popvae.py:389
-                        acc += 1.f + sv[k] - mu[k] * mu[k] - es;
-                        nxt[lr * PVN_LD + k] = zz;
-                        z_out[b * Kz + k] = zz;
+                        const float mu = cur[lr * PVN_LD + k], sv = cur[lr * PVN_LD + K + k];
+                        const float es = expf(sv);
+                        zz = mu + es * eps[b * K + k];  // exp(s), not exp(s/2): popvae.py:389
+                        acc += 1.f + sv - mu * mu - es;
                     }
+                    nxt[lr * PVN_LD + k] = zz;
+                    z_out[b * Kz + k] = zz;
+                }
                 kl_out[b] = -0.5f * acc;
             }
         } else if (n0 < N) {
@@ -460,30 +452,23 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
             if (tid < PVN_ROWS) {
                 const int lr = tid, b = rb + tid;  // row in LDS, row of the batch
                 const bool valid = b < nrows;
-                float dmu[16], dsv[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    dmu[k] = 0.f;
-                    dsv[k] = 0.f;
-                    if (k < K && valid) {
-                        const float mu = heads[b * Kh + k], s = heads[b * Kh + K + k];
-                        const float es = expf(s), d = cur[lr * PVN_LD + k];
-                        dmu[k] = d + mu * inv_b;
-                        dsv[k] = d * eps[b * K + k] * es + 0.5f * (es - 1.f) * inv_b;
-                    }
-                }
-                for (int k = 0; k < Kh; ++k) {
+                for (int k = 2 * K; k < Kh; ++k) {
                     nxt[lr * PVN_LD + k] = 0.f;
                     pvn_g(nx.dpre)[b * Kh + k] = 0.f;
                 }
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k < K) {
-                        nxt[lr * PVN_LD + k] = dmu[k];
-                        nxt[lr * PVN_LD + K + k] = dsv[k];
-                        pvn_g(nx.dpre)[b * Kh + k] = dmu[k];
-                        pvn_g(nx.dpre)[b * Kh + K + k] = dsv[k];
+                for (int k = 0; k < K; ++k) {  // (cur and nxt are different buffers)
+                    float dmu = 0.f, dsv = 0.f;
+                    if (valid) {
+                        const float mu = heads[b * Kh + k], s = heads[b * Kh + K + k];
+                        const float es = expf(s), d = cur[lr * PVN_LD + k];
+                        dmu = d + mu * inv_b;
+                        dsv = d * eps[b * K + k] * es + 0.5f * (es - 1.f) * inv_b;
                     }
+                    nxt[lr * PVN_LD + k] = dmu;
+                    nxt[lr * PVN_LD + K + k] = dsv;
+                    pvn_g(nx.dpre)[b * Kh + k] = dmu;
+                    pvn_g(nx.dpre)[b * Kh + K + k] = dsv;
+                }
             }
         } else if (n0 < op.kin) {
             const int Kin = op.kin, ks = op.nout >> 2;

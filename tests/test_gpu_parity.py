@@ -46,7 +46,13 @@ CASES = [
     (40, 700, 256, 3, 2, 32),      # two groups of 128 units (grouped wide decoder, per-layer narrow kernels)
     (40, 1000, 512, 2, 2, 19),     # four groups, short batch (C3 / grid-search width)
     (40, 500, 200, 2, 3, 32),      # width 200 padded to 256
-    (40, 600, 128, 2, 16, 25),     # 16 latent dimensions (the engine's maximum: the two heads fill one 32-column tile)
+    (40, 600, 128, 2, 16, 25),     # 16 latent dimensions: the two heads fill one 32-column tile
+    # --latent_dim is free in the reference (popvae.py:78-80); the engine takes up to 64 (heads = one layer of <= 128 outputs)
+    (40, 500, 128, 2, 24, 32),     # heads 48 -> 64 columns, z padded to 32
+    (40, 500, 64, 3, 40, 21),      # heads 80 -> 96 columns (wider than the hidden layers), z padded to 64
+    (40, 400, 128, 2, 64, 32),     # the maximum: heads exactly 128 columns
+    (40, 400, 256, 2, 40, 32),     # per-layer narrow kernels: separate sampling kernels (heads are not one 32-column tile)
+    (40, 300, 512, 2, 64, 17),
     (40, 400, 256, 1, 2, 32),      # depth 1 above width 128: the heads layer forms elu(P + b1) itself
     (40, 400, 512, 3, 16, 32),     # 16 latent dimensions: heads exactly 32 columns (sampling layer in the heads layer's tail)
     # the reference's default --depth_range is 3,6,10,20 (popvae.py:66-74, grid loop :280-369) and BASELINE config 5 has depth 8:
