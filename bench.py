@@ -291,7 +291,7 @@ def main():
                        "parallelism": (f"snp-shard x{world}, " + ("all-reduces enqueued by the engine (own RCCL communicator)"
                                                                    if native else "host-driven all-reduces (torch.distributed)"))
                        if sharded else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "pvk_dec (fused wide decoder: logits+sigmoid+BCE+dlogits+dV+Adam)",
+            "roofline": {"bound": "hbm", "kernel": "pvk_dec2 (fused wide decoder: logits+sigmoid+BCE+dlogits+dV+Adam; pvk_dec_grp above width 128)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo["dec"],

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""profiles/r01_pmc_traffic_C4.json from the two rocprofv3 --pmc passes of tools/gpu_profile.sh:
-python tools/pmc_traffic_json.py <FETCH_SIZE results.db> <WRITE_SIZE results.db> <out.json>
+"""profiles/rNN_pmc_traffic_<shape>.json from the two rocprofv3 --pmc passes of tools/gpu_profile.sh:
+python tools/pmc_traffic_json.py <FETCH_SIZE results.db> <WRITE_SIZE results.db> <out.json> [shape]
 Corrections (MI355X_MICROARCH.md, HBM section): both counters are in units of 1024 B; on gfx950 FETCH_SIZE tallies
 128-B requests at 64 B, so wide coalesced reads are doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores."""
 import json
 import sqlite3
 import sys
 
-KEYS = {"enc_fwd": "pvk_enc_fwd<", "dec": "pvk_dec<4, 1, 0>", "enc_bwd": "pvk_enc_bwd<4, 0, 1>", "dec_eval": "pvk_dec<4, 0, 0>"}
+KEYS = {"enc_fwd": "pvk_enc_fwd<", "dec": "pvk_dec2<4>", "enc_bwd": "pvk_enc_bwd<4, 0, 1>", "dec_eval": "pvk_dec<4, 0, 0>"}
+SHAPE = sys.argv[4] if len(sys.argv) > 4 else "C4"
 
 
 def avg(dbf, counter):
@@ -24,8 +25,8 @@ def avg(dbf, counter):
 
 
 f, w = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
-res = {"_about": "HBM traffic per launch at C4 (2504 x 1M SNPs, width 128): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
-                 "separate passes over `tools/kbench.py C4 12` (tools/gpu_profile.sh, tools/pmc_traffic_json.py). Counters are "
+res = {"_about": f"HBM traffic per launch at {SHAPE} (width 128): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
+                 f"separate passes over `tools/kbench.py {SHAPE} 12` (tools/gpu_profile.sh, tools/pmc_traffic_json.py). Counters are "
                  "in units of 1024 B; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so wide coalesced reads are doubled "
                  "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-B-per-lane streaming stores.",
        "kernels": {}}
