@@ -9,7 +9,7 @@ for wl in C4 C2; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt_$wl -o kt -- python3 bench.py --no-cpu-baseline --workload $wl > $OUT/bench_${wl}_under_rocprof.json 2> $OUT/kt_$wl.err || { tail -5 $OUT/kt_$wl.err; exit 1; }
   tail -1 $OUT/bench_${wl}_under_rocprof.json | cut -c1-200
   db=$(find $OUT/kt_$wl -name "*.db" | head -1)
-  [ -n "$db" ] && python3 tools/rocpd_stats.py $db --csv $OUT/kernel_stats_$wl.csv --skip 5 | head -8
+  [ -n "$db" ] && python3 tools/rocpd_stats.py $db --csv $OUT/kernel_stats_$wl.csv --skip 5
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -s KILL 200 rocprofv3 --pmc $c -d $OUT/pmc_${wl}_$c -o pmc -- python3 tools/kbench.py $wl 12 > $OUT/pmc_${wl}_$c.log 2>&1 || { tail -5 $OUT/pmc_${wl}_$c.log; exit 1; }
   done
