@@ -72,6 +72,11 @@ int pvae_reset_optimizer(pvae_engine* e);
 /* optimizer.lr (ReduceLROnPlateau, popvae.py:441-450) */
 int pvae_set_lr(pvae_engine* e, float lr);
 int pvae_get_lr(pvae_engine* e, float* lr);
+/* K5: which form of keras.losses.binary_crossentropy (popvae.py:417-418) the fused decoder pass computes:
+ * 0 (default) from the logits -- what Keras 2.15 does for a Sigmoid output in graph mode -- or 1 from probabilities clipped to
+ * [1e-7, 1 - 1e-7] (its other path; differs where |logit| > ~16: no gradient beyond the clip).  No counterpart flag in the
+ * reference: which path Keras takes is not visible there, so both are offered and tested against the oracle. */
+int pvae_set_bce_mode(pvae_engine* e, int mode);
 
 /* one train_step of vae.fit (popvae.py:490): rows = sample indices into the resident matrix (n <= batch_size),
  * eps = injected N(0,1) [n][latent_dim] or NULL for the engine's own stream.

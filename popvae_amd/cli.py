@@ -52,6 +52,9 @@ def build_parser():
     p.add_argument("--plot", default=False, action="store_true")
     p.add_argument("--metadata", default=None, help="path to tab-delimited metadata file with column 'sampleID'.")
     # not a flag of the reference: start from exported weights (a Keras <out>_weights.hdf5 / .npz), for per-step parity runs
+    p.add_argument("--bce_mode", default="logits", choices=("logits", "probs"),
+                   help="(popvae_amd) form of Keras' binary cross-entropy: from the logits (Keras in graph mode, default) or "
+                        "from probabilities clipped to [1e-7, 1 - 1e-7]; they differ where |logit| > 16")
     p.add_argument("--init_weights", default=None,
                    help="(popvae_amd) initialise the model from a Keras weight file (.hdf5) or .npz instead of glorot_uniform")
     return p
@@ -176,6 +179,7 @@ def main(argv=None):
                    seed=eng_seed, device_id=device_id)
         e.load_genotypes(packed)
         e.init_weights(eng_seed)
+        e.set_bce_mode(args.bce_mode)
         return e
 
     width, depth = args.width, args.depth
@@ -203,6 +207,7 @@ def main(argv=None):
                             batch_size=args.batch_size, seed=eng_seed, device_id=device_id)
         eng.load_genotypes(packed)
         eng.init_weights(eng_seed)
+        eng.eng.set_bce_mode(args.bce_mode)
     else:
         eng = make_single(width, depth)
     if args.init_weights:  # vae.load_weights before fit (per-step parity from a Keras export)

@@ -123,6 +123,7 @@ struct pvae_engine {
     float* d_loss = nullptr;  // [loss_cap][3]
     int64_t loss_cap = 0;
     float lr_host = 1e-3f;
+    int bce_probs = 0;  // pvae_set_bce_mode
     bool has_best = false;
     // SNP-axis sharding with the engine's own RCCL communicator (pvae_comm_init): the two all-reduces of a step are
     // enqueued on the engine's stream between the stages, no host code and no cross-stream events in between
@@ -1288,6 +1289,7 @@ int pvae_reset_optimizer(pvae_engine* e) {
     if (rc) return set_err(e, rc, "hipMemset failed");
     PvStep st0{};
     st0.lr = e->lr_host;
+    st0.bce_probs = e->bce_probs;
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(e->st, &st0, sizeof st0, hipMemcpyHostToDevice));
     return 0;
@@ -1327,6 +1329,14 @@ int pvae_set_lr(pvae_engine* e, float lr) {
     HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
+int pvae_set_bce_mode(pvae_engine* e, int mode) {
+    if (mode != 0 && mode != 1) return set_err(e, -2, "bce mode %d (0 = from logits, 1 = from clipped probabilities)", mode);
+    HIPCHK(hipStreamSynchronize(e->stream));  // the argument is a stack variable, and no step may be half way
+    HIPCHK(hipMemcpy(reinterpret_cast<char*>(e->st) + offsetof(PvStep, bce_probs), &mode, sizeof(int), hipMemcpyHostToDevice));
+    e->bce_probs = mode;
+    return 0;
+}
+
 int pvae_get_lr(pvae_engine* e, float* lr) {
     *lr = e->lr_host;
     return 0;

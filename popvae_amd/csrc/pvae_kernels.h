@@ -61,6 +61,8 @@ struct PvStep {  // device-resident per-step scalars (graph-replay friendly)
     int step_in_epoch;
     int acc;      // gradient dumps (MODE_GRAD): 0 = store, 1 = add to what is there (batches above 32 rows are
                   // processed as 32-row tiles whose gradients are accumulated before ONE Adam update)
+    int bce_probs;  // K5: 0 = binary cross-entropy from the logits (what Keras does for a Sigmoid output in graph
+                    // mode), 1 = from probabilities clipped to [1e-7, 1 - 1e-7] (Keras' other path).  pvae_set_bce_mode.
 };
 
 struct PvAdam {
@@ -85,6 +87,29 @@ __device__ __forceinline__ float pv_code(uint32_t lo, uint32_t hi, int r) {
     const uint32_t w = (r >> 3) ? hi : lo;
     const int sh = 2 * (r & 3) + 16 * ((r >> 2) & 1);
     return (float)((w >> sh) & 3u);
+}
+
+// One element of keras.losses.binary_crossentropy on the sigmoid output layer (popvae.py:407-409, 417-418) and its derivative
+// with respect to the logit z (not yet divided by the batch size); x = genotype value in {0, 0.5, 1}.
+//   probs == 0: from the logits, max(z,0) - z x + log(1 + exp(-|z|)),  d = sigmoid(z) - x;
+//   probs != 0: Keras' probability form in float32, -[x log(pc + 1e-7) + (1 - x) log(1 - pc + 1e-7)] with pc = clip(p, 1e-7,
+//               1 - 1e-7); the clip passes no gradient outside its range, d sigmoid / dz = p (1 - p).
+// The two differ only where |z| > ~16 (there the clipped form stops learning).  `probs` is uniform: a scalar branch.
+__device__ __forceinline__ void pv_bce(float z, float x, int probs, float& bce, float& d) {
+    const float e = __expf(-fabsf(z));                 // exp(-|z|)
+    const float inv = __builtin_amdgcn_rcpf(1.f + e);
+    const float p = z >= 0.f ? inv : e * inv;          // sigmoid(z)
+    if (!probs) {
+        bce = fmaxf(z, 0.f) - z * x + __logf(1.f + e);
+        d = p - x;
+    } else {
+        const float e7 = 1e-7f;
+        const float pc = fminf(fmaxf(p, e7), 1.f - e7);
+        const float a1 = pc + e7, a0 = 1.f - pc + e7;
+        bce = -(x * __logf(a1) + (1.f - x) * __logf(a0));
+        const bool inside = p >= e7 && p <= 1.f - e7;
+        d = inside ? ((1.f - x) * __builtin_amdgcn_rcpf(a0) - x * __builtin_amdgcn_rcpf(a1)) * (p * (1.f - p)) : 0.f;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -588,6 +613,7 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
     const int gw = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
+    const int bce_probs = st->bce_probs;
     const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
 
     PV_WT(0, 0);
@@ -643,13 +669,11 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
             const int b = PV_ROW(r, h);
             const float x = 0.5f * pv_code(lo, hi, r);
             const float z = a[r] + bias;
-            const float e = __expf(-fabsf(z));                 // exp(-|z|)
-            const float bce = fmaxf(z, 0.f) - z * x + __logf(1.f + e);
-            const float inv = __builtin_amdgcn_rcpf(1.f + e);
-            const float p = z >= 0.f ? inv : e * inv;            // sigmoid(z)
+            float bce, dz;
+            pv_bce(z, x, bce_probs, bce, dz);
             const bool ok = lvalid && (b < nrows);
             lossacc += ok ? bce : 0.f;
-            const float d = ok ? (p - x) * inv_b : 0.f;
+            const float d = ok ? dz * inv_b : 0.f;
             a[r] = d;
             dbias += d;
         }
@@ -811,6 +835,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
     const int per = (bgroups + gridDim.x - 1) / gridDim.x;
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
+    const int bce_probs = st->bce_probs;
     const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
 
     // per SNP block of the workgroup: [0] partial logits posted, [1] partial logits read (both only ever grow)
@@ -886,13 +911,11 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
             const int b = PV_ROW(r, h);
             const float x = 0.5f * pv_code(lo, hi, r);
             const float z = a[r] + bias;
-            const float e = __expf(-fabsf(z));
-            const float bce = fmaxf(z, 0.f) - z * x + __logf(1.f + e);
-            const float inv = __builtin_amdgcn_rcpf(1.f + e);
-            const float p = z >= 0.f ? inv : e * inv;
+            float bce, dz;
+            pv_bce(z, x, bce_probs, bce, dz);
             const bool ok = lvalid && (b < nrows);
             lossacc += (ok && grp == 0) ? bce : 0.f;
-            const float d = ok ? (p - x) * inv_b : 0.f;
+            const float d = ok ? dz * inv_b : 0.f;
             a[r] = d;
             dbias += d;
         }
@@ -1051,6 +1074,7 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
     const float* mb0 = smem + 32 * LDG + (bsub * NWB) * (2 * 32 * 33);  // mailbox of block column 0 of this SNP block
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
+    const int bce_probs = st->bce_probs;
     __shared__ int blk_sync[BPI][2];  // [0] partial logits posted, [1] partial logits read (both only ever grow)
     if (tid < 2 * BPI) blk_sync[tid >> 1][tid & 1] = 0;
     bool sync_ok = true;
@@ -1153,13 +1177,11 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
             const int b = PV_ROW(r, h);
             const float x = 0.5f * pv_code(lo, hi, r);
             const float z = a[r] + bias;
-            const float e = __expf(-fabsf(z));                 // exp(-|z|)
-            const float bce = fmaxf(z, 0.f) - z * x + __logf(1.f + e);
-            const float inv = __builtin_amdgcn_rcpf(1.f + e);
-            const float p = z >= 0.f ? inv : e * inv;            // sigmoid(z)
+            float bce, dz;
+            pv_bce(z, x, bce_probs, bce, dz);
             const bool ok = lvalid && (b < nrows);
             lossacc += (ok && w == 0) ? bce : 0.f;
-            const float d = ok ? (p - x) * inv_b : 0.f;
+            const float d = ok ? dz * inv_b : 0.f;
             a[r] = d;
             dbias += d;
         }

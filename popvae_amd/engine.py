@@ -17,7 +17,7 @@ _lib = None
 ENGINE_SYMBOLS = [
     "pvae_version", "pvae_device_count", "pvae_create", "pvae_destroy", "pvae_last_error", "pvae_set_stream",
     "pvae_synchronize", "pvae_load_genotypes", "pvae_num_tensors", "pvae_tensor_shape", "pvae_set_tensor",
-    "pvae_get_tensor", "pvae_init_weights", "pvae_get_moment", "pvae_reset_optimizer", "pvae_set_lr", "pvae_get_lr",
+    "pvae_get_tensor", "pvae_init_weights", "pvae_get_moment", "pvae_reset_optimizer", "pvae_set_lr", "pvae_get_lr", "pvae_set_bce_mode",
     "pvae_train_step", "pvae_train_step_noalloc", "pvae_eval_step", "pvae_grad_step", "pvae_get_grad", "pvae_train_epoch", "pvae_encode",
     "pvae_decode", "pvae_pca_gram", "pvae_snapshot_best", "pvae_restore_best", "pvae_exchange_buffer", "pvae_exchange_copy", "pvae_stage_a", "pvae_stage_b",
     "pvae_stage_c", "pvae_stage_c_next", "pvae_stage_encode", "pvae_set_timing", "pvae_get_timing", "pvae_set_timing_only",
@@ -65,6 +65,7 @@ def lib():
         L.pvae_get_moment.argtypes = [vp, C.c_int, C.c_int, _f32p, i64]
         L.pvae_reset_optimizer.argtypes = [vp]
         L.pvae_set_lr.argtypes = [vp, C.c_float]
+        L.pvae_set_bce_mode.argtypes = [vp, C.c_int]
         L.pvae_get_lr.argtypes = [vp, C.POINTER(C.c_float)]
         for f in (L.pvae_train_step, L.pvae_train_step_noalloc, L.pvae_eval_step, L.pvae_grad_step):
             f.argtypes = [vp, _i32p, i32, _fopt, _fopt]
@@ -209,6 +210,10 @@ class Engine:
         self._ck(lib().pvae_set_lr(self._h, float(v)))
 
     # -- steps -----------------------------------------------------------------------------------
+    def set_bce_mode(self, mode):
+        """'logits' (default) or 'probs': which form of Keras' binary cross-entropy the decoder pass computes (K5)."""
+        self._ck(lib().pvae_set_bce_mode(self._h, {"logits": 0, "probs": 1}[mode]))
+
     def _step(self, fn, rows, eps, want_loss):
         rows = np.ascontiguousarray(rows, dtype=np.int32)
         eps = _f32(eps)

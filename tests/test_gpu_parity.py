@@ -382,3 +382,45 @@ def test_staged_step_with_promised_next_batch():
     # Adam turns a gradient difference d on a near-zero gradient into lr * d / eps of weight difference
     for i, (a, b) in enumerate(zip(wa, wb)):
         assert np.abs(a - b).max() <= 1e-5, (i, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("N,L,W,D,K,n", [(40, 900, 128, 3, 2, 32), (40, 500, 64, 2, 3, 19), (40, 600, 256, 2, 2, 32), (40, 400, 512, 2, 2, 27)])
+def test_bce_from_clipped_probabilities(N, L, W, D, K, n):
+    """K5: Keras' other binary cross-entropy path (probabilities clipped to [1e-7, 1 - 1e-7]) against the oracle's 'probs'
+    mode -- loss and every gradient tensor through the gradient-dump kernels, and the training kernels (pvk_dec2 /
+    pvk_dec_grp) through the first Adam moment.  A fifth of the output biases is pushed to +-25 so that the clip is active:
+    those SNPs contribute -log(2e-7) or ~0 to the loss and pass no gradient."""
+    dc, w = _problem(N, L, W, D, K, seed=L + W + 1)
+    g = np.random.default_rng(2)
+    w = [x.copy() for x in w]
+    sat = g.random(L) < 0.2
+    w[-1] = np.where(sat, np.where(g.random(L) < 0.5, 25.0, -25.0), w[-1]).astype(w[-1].dtype)
+    rows = g.choice(N, n, replace=False).astype(np.int32)
+    eps = g.normal(size=(n, K))
+    e = _mk(dc, w, W, D, K)
+    e.set_bce_mode("probs")
+    w32 = [x.astype(np.float32).astype(np.float64) for x in w]
+    c = O.forward(w32, dc[rows], eps.astype(np.float32).astype(np.float64), D, K, bce_mode="probs")
+    grads = O.backward(w32, c, D, K, bce_mode="probs")
+    c_log = O.forward(w32, dc[rows], eps.astype(np.float32).astype(np.float64), D, K)
+    assert abs(c["loss"] - c_log["loss"]) > 1e-3 * abs(c["loss"])  # the two forms do differ on this input
+    loss, recon, kl = e.grad_step(rows, eps)
+    # The loss is compared with the oracle evaluated in float32, as Keras evaluates it: 1 - 1e-7 is 1 - 1.19e-7 there, so a
+    # saturated wrong-side element costs -log(2.19e-7) = 15.33, not the -log(2e-7) = 15.42 of a float64 evaluation.  (The
+    # gradients do not depend on that: such elements are outside the clip in both.)
+    w_f32 = [x.astype(np.float32) for x in w]
+    c32 = O.forward(w_f32, dc[rows].astype(np.float32), eps.astype(np.float32), D, K, bce_mode="probs")
+    assert abs(loss - c32["loss"]) <= RTOL * abs(c32["loss"]), (loss, c32["loss"], c["loss"])
+    for i, (a, b) in enumerate(zip(e.get_grads(), grads)):
+        assert _relerr(a, b) <= RTOL, (i, _relerr(a, b))
+    l2, _, _ = e.eval_step(rows, eps)
+    assert abs(l2 - loss) <= 1e-6 * abs(loss)
+    l3, _, _ = e.train_step(rows, eps)
+    assert abs(l3 - loss) <= 1e-6 * abs(loss)
+    for i, (a, b) in enumerate(zip(e.get_moments(0), grads)):
+        assert _relerr(a.astype(np.float64) * 10.0, b) <= RTOL, ("m", i, _relerr(a.astype(np.float64) * 10.0, b))
+    e.set_bce_mode("logits")
+    e.set_weights(w)
+    l4, _, _ = e.eval_step(rows, eps)
+    assert abs(l4 - c_log["loss"]) <= RTOL * abs(c_log["loss"])
+    e.close()
