@@ -42,6 +42,8 @@ CASES = [
     (50, 3887, 128, 6, 2, 21),     # short last batch (85 % 32 = 21)
     (40, 777, 64, 3, 3, 7),        # ragged L, W = 64, K = 3
     (40, 300, 100, 2, 5, 32),      # width padded 100 -> 128
+    (40, 900, 96, 3, 2, 32),       # three block columns: pvk_dec2 on 3-wave workgroups, encoder grids in multiples of 3
+    (45, 2100, 80, 2, 2, 13),      # width 80 padded to 96, ragged L, short batch
     (33, 31, 32, 1, 1, 1),         # L < one block, depth 1, single row
     (40, 700, 256, 3, 2, 32),      # two groups of 128 units (grouped wide decoder, per-layer narrow kernels)
     (40, 1000, 512, 2, 2, 19),     # four groups, short batch (C3 / grid-search width)
@@ -125,7 +127,8 @@ def test_weight_roundtrip_and_layouts():
 
 
 @pytest.mark.parametrize("L,W,D", [(1000, 128, 3), (3887, 128, 6), (900, 256, 3), (700, 512, 2),
-                                   (600, 128, 20), (600, 128, 10), (500, 256, 20), (400, 512, 8)])
+                                   (600, 128, 20), (600, 128, 10), (500, 256, 20), (400, 512, 8),
+                                   (1100, 96, 3), (1300, 64, 2), (2000, 32, 2)])  # 3 / 2 / 1 block columns per subtile
 def test_adam_training_steps_match_oracle(L, W, D):
     """Five fused-Adam train steps (incl. a short batch) vs oracle float64 Keras-Adam."""
     N, K = 64, 2
