@@ -103,6 +103,10 @@ struct pvae_engine {
     float* h_out3 = nullptr;       // pinned staging of {loss, recon, kl}
     int enc_wgs = 0, dec_wgs = 0, encb_wgs = 0, dec_eval_wgs = 0;
     int dec2_wgs = 0;          // plain training pass at widths up to 128: pvk_dec2 (0 = use pvk_dec)
+    // Batches of 33 .. 128 rows in ONE weight pass (width 128, one rank): T = 2 or 4 row tiles of 32 go through the wide
+    // kernels' <.., T> instantiations and 2 T chain workers; activation buffers hold 32 T rows.  T == 1: off.
+    int T = 1;
+    int dec2t_wgs = 0;         // grid of pvk_dec2<4, T> (one 8-wave workgroup per CU)
     int encb_parts = 0;        // partial tiles [32][Wp] the fused forward of pvk_enc_bwd leaves in encpart (one per subtile slot)
     int64_t encpart_floats = 0;
     int64_t tile_floats = 0;
@@ -322,6 +326,13 @@ int setup_kernel_attrs(pvae_engine* e) {
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN, 1>), lds_enc_bwd(e->Wp)));        \
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_GRAD, 0>), lds_enc_bwd(e->Wp)));         \
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN_ACC, 0>), lds_enc_bwd(e->Wp)));
+    if (e->T == 2) {
+        HIPCHK(allow_lds((pvk_dec2<4, 2>), (PvDec2<4, 2>::lds())));
+        HIPCHK(allow_lds((pvk_enc_bwd<4, PV_MODE_TRAIN, 0, 2>), 2 * lds_enc_bwd(e->Wp)));
+    } else if (e->T == 4) {
+        HIPCHK(allow_lds((pvk_dec2<4, 4>), (PvDec2<4, 4>::lds())));
+        HIPCHK(allow_lds((pvk_enc_bwd<4, PV_MODE_TRAIN, 0, 4>), 4 * lds_enc_bwd(e->Wp)));
+    }
     switch (e->NWB) {
         case 1: PV_ATTR(1) break;
         case 2: PV_ATTR(2) break;
@@ -469,7 +480,7 @@ int build_bwd_ops(pvae_engine* e, bool grad, PvBwdOp** out) {
         PvBwdOp o{};
         if (nd == e->dpre_bufs.size()) {
             float* p = nullptr;
-            if (hipMalloc(&p, (size_t)32 * d.nout * sizeof(float)) != hipSuccess) p = nullptr;
+            if (hipMalloc(&p, (size_t)32 * e->T * d.nout * sizeof(float)) != hipSuccess) p = nullptr;
             e->dpre_bufs.push_back(p);
         }
         o.dpre = e->dpre_bufs[nd++];
@@ -534,12 +545,12 @@ int ensure_narrow_packed(pvae_engine* e) {
     return launch_check(e, "narrow_pack");
 }
 
-int narrow_fused_fwd(pvae_engine* e, bool encoder_only, bool decoder_only = false) {
+int narrow_fused_fwd(pvae_engine* e, bool encoder_only, bool decoder_only = false, int tiles = 1) {
     int rc0;
     if ((rc0 = ensure_narrow_packed(e))) return rc0;
-    const int nops = encoder_only ? e->n_enc_ops : e->n_fwd_ops;
-    hipLaunchKernelGGL(pvk_narrow_fwd, dim3(e->narrow_warm ? 8 * (nops + 1) : PVN_WORKERS), dim3(PVN_THREADS), pvn_lds_fwd(), e->stream,
-                       e->d_fwd_ops, decoder_only ? e->n_enc_ops : 0, nops, e->P, e->eps, e->K, e->Kz, e->z, e->kl);
+    const int nops = encoder_only ? e->n_enc_ops : e->n_fwd_ops, nworkers = PVN_WORKERS * tiles;
+    hipLaunchKernelGGL(pvk_narrow_fwd, dim3(e->narrow_warm ? 8 * (nops + 1) : nworkers), dim3(PVN_THREADS), pvn_lds_fwd(), e->stream,
+                       e->d_fwd_ops, decoder_only ? e->n_enc_ops : 0, nops, e->P, e->eps, e->K, e->Kz, e->z, e->kl, nworkers);
     return launch_check(e, "narrow_fwd");
 }
 
@@ -712,7 +723,7 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
         const dim3 chain_grid(mode == 1 ? 1 : e->narrow_warm ? 8 * (e->n_bwd_ops + 1) : PVN_WORKERS);
 #define PV_NARROW_BWD(MD)                                                                                                      \
     hipLaunchKernelGGL(pvk_narrow_bwd<MD>, chain_grid, dim3(PVN_THREADS), pvn_lds_bwd(), e->stream, table, e->n_bwd_ops, e->xch1, \
-                       e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st, e->adam, d_out3, mode == 1 ? 0 : 1)
+                       e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st, e->adam, d_out3, mode == 1 ? 0 : 1, (int)PVN_WORKERS)
         if (km == PV_MODE_GRAD) PV_NARROW_BWD(PV_MODE_GRAD);
         else if (km == PV_MODE_TRAIN_ACC) PV_NARROW_BWD(PV_MODE_TRAIN_ACC);
         else PV_NARROW_BWD(PV_MODE_TRAIN);
@@ -807,31 +818,31 @@ int check_rows(pvae_engine* e, const int32_t* rows, int64_t n) {
 }
 
 // upload rows/eps for a single batch and run pvk_step_begin
-constexpr size_t kSlotBytes = 32 * sizeof(int) + 32 * 64 * sizeof(float);  // 32 rows + their noise at latent_dim <= 64
-int begin_batch(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, bool train) {
+constexpr size_t kSlotBytes = 128 * sizeof(int) + 128 * 64 * sizeof(float);  // 128 rows + their noise at latent_dim <= 64
+int begin_batch(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, bool train, int max_rows = 32) {
     int rc;
     if (n <= 0 || n > e->cfg.batch_size) return set_err(e, -2, "batch of %d rows (batch_size %d)", n, e->cfg.batch_size);
-    if (n > 32) return set_err(e, -2, "a device pass takes at most 32 rows (got %d): larger batches go through pvae_train_step / "
-                                      "pvae_train_epoch, which tile them", n);
+    if (n > max_rows) return set_err(e, -2, "a device pass takes at most %d rows (got %d): larger batches go through pvae_train_step / "
+                                            "pvae_train_epoch, which tile them", max_rows, n);
     if (!e->geno) return set_err(e, -3, "no genotypes loaded (pvae_load_genotypes)");
     if ((rc = check_rows(e, rows, n))) return rc;
-    if ((rc = ensure_rows(e, 64))) return rc;
+    if ((rc = ensure_rows(e, 128))) return rc;
     pvae_engine::Slot& sl = e->slots[e->slot_next];  // pinned ring, allocated by pvae_create
     e->slot_next = (e->slot_next + 1) % 8;
     if (sl.pending) HIPCHK(hipEventSynchronize(sl.ev));
     memcpy(sl.host, rows, n * sizeof(int));
-    if (eps) memcpy(sl.host + 32 * sizeof(int), eps, (size_t)n * e->K * sizeof(float));
+    if (eps) memcpy(sl.host + 128 * sizeof(int), eps, (size_t)n * e->K * sizeof(float));
     HIPCHK(hipMemcpyAsync(e->d_rows, sl.host, n * sizeof(int), hipMemcpyHostToDevice, e->stream));
     if (eps)
         hipLaunchKernelGGL(pvk_step_begin, dim3(1), dim3(64), 0, e->stream, e->st, (const int*)nullptr, n, e->cfg.batch_size, 0,
                            train ? 1 : 0, e->adam.b1, e->adam.b2);
     else
         hipLaunchKernelGGL(pvk_step_begin_eps, dim3(1), dim3(1024), 0, e->stream, e->st, (const int*)nullptr, n,
-                           e->cfg.batch_size, 0, train ? 1 : 0, e->adam.b1, e->adam.b2, e->eps, 32 * e->K, e->cfg.seed,
+                           e->cfg.batch_size, 0, train ? 1 : 0, e->adam.b1, e->adam.b2, e->eps, max_rows * e->K, e->cfg.seed,
                            e->d_counter);
     if ((rc = launch_check(e, "step_begin"))) return rc;
     if (eps) {
-        HIPCHK(hipMemcpyAsync(e->eps, sl.host + 32 * sizeof(int), (size_t)n * e->K * sizeof(float), hipMemcpyHostToDevice,
+        HIPCHK(hipMemcpyAsync(e->eps, sl.host + 128 * sizeof(int), (size_t)n * e->K * sizeof(float), hipMemcpyHostToDevice,
                               e->stream));
         HIPCHK(hipEventRecord(sl.ev, e->stream));
         sl.pending = true;
@@ -848,6 +859,66 @@ int fetch_out3(pvae_engine* e, float* out3) {
     HIPCHK(hipStreamSynchronize(e->stream));
     memcpy(out3, e->h_out3, 3 * sizeof(float));
     return 0;
+}
+
+// A train step on 33 .. 32 T rows in ONE pass over the wide weights (rows on the device at d_rows[row_offset ..], PvStep and
+// the noise set up by the caller): every kernel of the step sees T row tiles -- the wide kernels multiply the block they
+// hold with each tile's codes and sum dW / dV over the tiles before the one Adam update, the chain runs 2 T workers.
+template <int T>
+int multi_tile_launches(pvae_engine* e, int row_offset, float* d_out3) {
+    int rc;
+    const int R = 32 * T, nR = R * e->Wp;
+    {
+        Timer t(e, C_GATHER);
+        hipLaunchKernelGGL(pvk_gather_transpose, dim3(((e->nblk + 1) / 2 + 3) / 4, T), dim3(256), 0, e->stream, e->geno, e->row_bytes,
+                           e->d_rows, e->st, row_offset, e->nblk, e->Xt);
+        if ((rc = launch_check(e, "gather_transpose"))) return rc;
+    }
+    {
+        Timer t(e, C_ENC_FWD);
+        hipLaunchKernelGGL((pvk_enc_fwd<4, T>), dim3(e->enc_wgs), dim3(256), 0, e->stream, e->W1.w, e->geno, e->row_bytes, e->d_rows,
+                           e->st, row_offset, e->nblk, e->ngrp, e->encpart, e->ts4);
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(nR)), dim3(256), 0, e->stream, e->encpart, e->encb_parts, nR, 0.5f,
+                           e->P, (const float*)nullptr, (float*)nullptr);
+        if ((rc = launch_check(e, "enc_fwd"))) return rc;
+    }
+    {
+        Timer t(e, C_NARROW_FWD);
+        if ((rc = narrow_fused_fwd(e, false, false, T))) return rc;
+    }
+    {
+        Timer t(e, C_DEC);
+        hipLaunchKernelGGL((pvk_dec2<4, T>), dim3(e->dec2t_wgs), dim3(PvDec2<4, T>::NW * 64), (PvDec2<4, T>::lds()), e->stream,
+                           (const float*)e->Vout.w, (const float*)e->Vout.m, (const float*)e->Vout.v, e->Vout.w2, e->Vout.m2, e->Vout.v2,
+                           e->cout.w, e->cout.m, e->cout.v, (const float*)e->g[e->D - 1], (const uint64_t*)e->Xt, e->nblk, (int)e->L,
+                           (const PvStep*)e->st, e->adam, e->dgpart, e->losspart, e->ts4);
+        e->Vout.swap();
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(nR)), dim3(256), 0, e->stream, e->dgpart, e->dec2t_wgs, nR, 1.0f,
+                           e->xch1, e->losspart, e->xch1 + nR);
+        if ((rc = launch_check(e, "dec"))) return rc;
+    }
+    {
+        Timer t(e, C_NARROW_BWD);
+        if ((rc = ensure_narrow_packed(e))) return rc;
+        hipLaunchKernelGGL(pvk_narrow_bwd<PV_MODE_TRAIN>, dim3(e->narrow_warm ? 8 * (e->n_bwd_ops + 1) : PVN_WORKERS * T),
+                           dim3(PVN_THREADS), pvn_lds_bwd(), e->stream, (const PvBwdOp*)e->d_bwd_ops, e->n_bwd_ops, e->xch1, e->Wp, e->kl,
+                           e->eps, e->headout, e->Kh, e->K, e->st, e->adam, d_out3, 1, (int)PVN_WORKERS * T);
+        if ((rc = launch_check(e, "narrow_bwd"))) return rc;
+    }
+    {
+        Timer t(e, C_ENC_BWD);
+        const int adam_units = 16 * e->n_bwd_ops, adam_wgs = (adam_units + 3) / 4;
+        hipLaunchKernelGGL((pvk_enc_bwd<4, PV_MODE_TRAIN, 0, T>), dim3(e->encb_wgs + adam_wgs), dim3(256), T * lds_enc_bwd(e->Wp),
+                           e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2, e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp,
+                           e->st, e->adam, (const uint8_t*)nullptr, (int64_t)0, (const int*)nullptr, 0, 0, (float*)nullptr, e->ts4,
+                           (const float*)nullptr, (const PvBwdOp*)e->d_bwd_ops, adam_units);
+        e->W1.swap();
+        if ((rc = launch_check(e, "enc_bwd"))) return rc;
+    }
+    return 0;
+}
+int multi_tile_train(pvae_engine* e, int row_offset, float* d_out3) {
+    return e->T == 2 ? multi_tile_launches<2>(e, row_offset, d_out3) : multi_tile_launches<4>(e, row_offset, d_out3);
 }
 
 // one 32-row tile of a larger batch (rows already on the device at d_rows[row_offset..]): forward, loss part,
@@ -881,6 +952,12 @@ int full_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, 
         if ((rc = stage_b(e, mode))) return rc;
         if ((rc = shard_allreduce(e, 1))) return rc;
         if ((rc = stage_c(e, mode, e->d_loss))) return rc;
+        return fetch_out3(e, out3);
+    }
+    if (mode == 0 && e->T > 1 && n <= 32 * e->T) {  // one weight pass for the whole batch
+        if ((rc = ensure_loss(e, 1))) return rc;
+        if ((rc = begin_batch(e, rows, n, eps, true, 32 * e->T))) return rc;
+        if ((rc = multi_tile_train(e, 0, e->d_loss))) return rc;
         return fetch_out3(e, out3);
     }
     const int nt = (n + 31) / 32;
@@ -1081,24 +1158,29 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     T.push_back({T_COUT, 0, e->L, 0});
 
     // activations / scratch
-    const int64_t act_n = 32 * (int64_t)std::max(e->Wp, std::max(e->Kh, e->Kz));
-    CK(allocf(e, &e->P, 32 * e->Wp));
+    // batches of 33 .. 128 rows in one weight pass: width 128 (four block columns, the fused chain), one rank
+    if (cfg->batch_size > 32 && cfg->batch_size <= 128 && e->Wp == 128 && cfg->world == 1 && 2 * e->D + 2 <= PVN_MAXOPS &&
+        !getenv("PVAE_NO_FUSED_NARROW") && !getenv("PVAE_NO_DEC2") && !getenv("PVAE_NO_MULTITILE"))
+        e->T = cfg->batch_size <= 64 ? 2 : 4;
+    const int64_t R = 32 * (int64_t)e->T;  // rows the activation buffers hold
+    const int64_t act_n = R * (int64_t)std::max(e->Wp, std::max(e->Kh, e->Kz));
+    CK(allocf(e, &e->P, R * e->Wp));
     e->h.resize(e->D);
     e->g.resize(e->D);
-    for (auto& p : e->h) CK(allocf(e, &p, 32 * e->Wp));
-    for (auto& p : e->g) CK(allocf(e, &p, 32 * e->Wp));
-    CK(allocf(e, &e->headout, 32 * e->Kh));
-    CK(allocf(e, &e->dheads, 32 * e->Kh));
-    CK(allocf(e, &e->z, 32 * e->Kz));
-    CK(allocf(e, &e->dz, 32 * e->Kz));
-    CK(allocf(e, &e->kl, 32));
-    CK(allocf(e, &e->eps, 32 * e->K));
-    CK(allocf(e, &e->xch1, 32 * e->Wp + 32));
+    for (auto& p : e->h) CK(allocf(e, &p, R * e->Wp));
+    for (auto& p : e->g) CK(allocf(e, &p, R * e->Wp));
+    CK(allocf(e, &e->headout, R * e->Kh));
+    CK(allocf(e, &e->dheads, R * e->Kh));
+    CK(allocf(e, &e->z, R * e->Kz));
+    CK(allocf(e, &e->dz, R * e->Kz));
+    CK(allocf(e, &e->kl, R));
+    CK(allocf(e, &e->eps, R * e->K));
+    CK(allocf(e, &e->xch1, R * e->Wp + 32));
     CK(allocf(e, &e->dA, act_n));
     CK(allocf(e, &e->dB, act_n));
-    CK(allocf(e, &e->dpre1, 32 * e->Wp));
-    HK(hipMalloc(&e->Xt, e->Lp * sizeof(uint64_t)));
-    HK(hipMemsetAsync(e->Xt, 0, e->Lp * sizeof(uint64_t), e->stream));
+    CK(allocf(e, &e->dpre1, R * e->Wp));
+    HK(hipMalloc(&e->Xt, e->T * e->Lp * sizeof(uint64_t)));
+    HK(hipMemsetAsync(e->Xt, 0, e->T * e->Lp * sizeof(uint64_t), e->stream));
 
     auto clampi = [](int64_t v, int64_t lo, int64_t hi) { return (int)std::min(hi, std::max(lo, v)); };
     CK(setup_kernel_attrs(e));
@@ -1170,11 +1252,19 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
             fprintf(stderr, "[pvae] CUs %d; blocks/CU dec %d enc_bwd %d; grids enc_fwd %d dec %d enc_bwd %d (+ Adam workgroups), dec eval %d\n", cus, o_dec, o_encb,
                     e->enc_wgs, e->dec_wgs, e->encb_wgs, e->dec_eval_wgs);
     }
-    e->encpart_floats = (int64_t)e->encb_parts * 32 * e->Wp;
-    CK(allocf(e, &e->encpart, e->encpart_floats));
+    e->encpart_floats = (int64_t)e->encb_parts * 32 * e->Wp;  // what a one-tile pass needs (pvae_train_step_noalloc)
+    CK(allocf(e, &e->encpart, e->encpart_floats * e->T));
+    if (e->T > 1) {
+        hipDeviceProp_t prop2;
+        HK(hipGetDeviceProperties(&prop2, e->dev));
+        int occ = 1;
+        if (e->T == 2) HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (pvk_dec2<4, 2>), 256, (PvDec2<4, 2>::lds())));
+        else HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (pvk_dec2<4, 4>), 256, (PvDec2<4, 4>::lds())));
+        e->dec2t_wgs = std::max(1, std::min((prop2.multiProcessorCount > 0 ? prop2.multiProcessorCount : 256) * std::max(occ, 1), e->nblk));
+    }
     e->fuse_fwd = !getenv("PVAE_NO_FUSE_FWD");
-    CK(allocf(e, &e->dgpart, (int64_t)std::max(e->dec_wgs, e->dec2_wgs) * 32 * e->Wp));
-    CK(allocf(e, &e->losspart, (int64_t)std::max(std::max(e->dec_wgs, e->dec2_wgs), e->dec_eval_wgs)));
+    CK(allocf(e, &e->dgpart, std::max((int64_t)std::max(e->dec_wgs, e->dec2_wgs) * 32 * e->Wp, (int64_t)e->dec2t_wgs * 32 * e->T * e->Wp)));
+    CK(allocf(e, &e->losspart, (int64_t)std::max(std::max(std::max(e->dec_wgs, e->dec2_wgs), e->dec_eval_wgs), e->dec2t_wgs)));
 
     HK(hipMalloc(&e->st, sizeof(PvStep)));
     PvStep st0{};
@@ -1407,6 +1497,12 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
             HIPCHK(hipMemsetAsync(slot, 0, (size_t)3 * tp * sizeof(float), e->stream));
             hipLaunchKernelGGL(pvk_step_begin, dim3(1), dim3(64), 0, e->stream, e->st, (const int*)nullptr, nb, B, 0, phase == 0 ? 1 : 0,
                                e->adam.b1, e->adam.b2);
+            if (phase == 0 && e->T > 1 && nb > 32) {  // the whole batch in one weight pass
+                hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, 32 * e->T * e->K, e->cfg.seed, e->d_counter);
+                if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
+                if ((rc = multi_tile_train(e, base + s * B, slot))) return rc;
+                continue;
+            }
             for (int t = 0; t * 32 < nb; ++t) {
                 hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, 32 * e->K, e->cfg.seed, e->d_counter);
                 if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;

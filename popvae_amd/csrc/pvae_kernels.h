@@ -94,12 +94,20 @@ __device__ __forceinline__ float pv_code(uint32_t lo, uint32_t hi, int r) {
 //   probs == 0: from the logits, max(z,0) - z x + log(1 + exp(-|z|)),  d = sigmoid(z) - x;
 //   probs != 0: Keras' probability form in float32, -[x log(pc + 1e-7) + (1 - x) log(1 - pc + 1e-7)] with pc = clip(p, 1e-7,
 //               1 - 1e-7); the clip passes no gradient outside its range, d sigmoid / dz = p (1 - p).
-// The two differ only where |z| > ~16 (there the clipped form stops learning).  `probs` is uniform: a scalar branch.
-__device__ __forceinline__ void pv_bce(float z, float x, int probs, float& bce, float& d) {
+// The two differ only where |z| > ~16 (there the clipped form stops learning).  The mode is uniform: the callers branch
+// once around their 16-value loop (a branch per value cost the grouped decoder 12 more spilled registers).
+// -DPV_BCE_LOGITS_ONLY: builds without the switch (A/B of what it costs)
+#ifdef PV_BCE_LOGITS_ONLY
+#define PV_BCE_MODE(st) 0
+#else
+#define PV_BCE_MODE(st) ((st)->bce_probs)
+#endif
+template <int PROBS>
+__device__ __forceinline__ void pv_bce(float z, float x, float& bce, float& d) {
     const float e = __expf(-fabsf(z));                 // exp(-|z|)
     const float inv = __builtin_amdgcn_rcpf(1.f + e);
     const float p = z >= 0.f ? inv : e * inv;          // sigmoid(z)
-    if (!probs) {
+    if (!PROBS) {
         bce = fmaxf(z, 0.f) - z * x + __logf(1.f + e);
         d = p - x;
     } else {
@@ -178,7 +186,10 @@ __device__ __forceinline__ void pv_gather_block(const uint8_t* __restrict__ geno
 __global__ __launch_bounds__(256) void pvk_gather_transpose(const uint8_t* __restrict__ geno, int64_t row_bytes,
                                                             const int* __restrict__ rows, const PvStep* st,
                                                             int row_offset, int nblk, uint64_t* __restrict__ Xt) {
-    pv_gather_block(geno, row_bytes, rows, st->nrows, row_offset, nblk, Xt, blockIdx.x);
+    // blockIdx.y = 32-row tile of the device pass: its rows follow the previous tile's, its words the previous tile's array
+    const int tile = blockIdx.y;
+    pv_gather_block(geno, row_bytes, rows, max(0, min(32, st->nrows - 32 * tile)), row_offset + 32 * tile, nblk,
+                    Xt + (int64_t)tile * nblk * 32, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -189,7 +200,9 @@ __global__ __launch_bounds__(256) void pvk_gather_transpose(const uint8_t* __res
 // number of workgroups as that pass, both produce bit-identical partial tiles (same products in the same order), which
 // pvk_reduce_parts sums in a fixed order: a step computes the same numbers whichever of the two paths fed it.
 // ---------------------------------------------------------------------------------------------
-template <int NWB>
+// T = 32-row tiles of the device pass (1; 2 or 4 for a batch above 32 rows in ONE weight pass: the block is requested once
+// and multiplied with every tile's codes).  Rows of tile t are rows[row_offset + 32 t ..]; the partial tile is [32 T][Wp].
+template <int NWB, int T = 1>
 __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1, const uint8_t* __restrict__ geno,
                                                    int64_t row_bytes, const int* __restrict__ rows,
                                                    const PvStep* st, int row_offset, int nblk, int ngrp,
@@ -200,31 +213,38 @@ __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1,
     const int slot = gw / NWB, w = gw - slot * NWB;
     const int nslots = (gridDim.x / ngrp) * 4 / NWB;  // the host sizes the grid so that this divides
     const int nrows = st->nrows;
-    const uint8_t* xrow = nullptr;
-    if (c < nrows) xrow = geno + (int64_t)rows[row_offset + c] * row_bytes;
+    const uint8_t* xrow[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) xrow[t] = 32 * t + c < nrows ? geno + (int64_t)rows[row_offset + 32 * t + c] * row_bytes : nullptr;
 
-    f32x16 acc;
+    f32x16 acc[T];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    auto mma = [&](const f32x4 (&wv)[4], uint64_t xw) {
-        xw >>= (8 * h);
-        const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
+    for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv_code(lo, hi, r), wv[r >> 2][r & 3], acc, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    auto mma = [&](const f32x4 (&wv)[4], const uint64_t (&xw)[T]) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const uint64_t xs = xw[t] >> (8 * h);
+            const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv_code(lo, hi, r), wv[r >> 2][r & 3], acc[t], 0, 0, 0);
+        }
     };
-    auto request = [&](f32x4 (&wv)[4], uint64_t& xw, int blk_) {
+    auto request = [&](f32x4 (&wv)[4], uint64_t (&xw)[T], int blk_) {
         const f32x4* tile = reinterpret_cast<const f32x4*>(W1) + ((int64_t)blk_ * ngrp + grp) * ts + w * 256 + lane;
 #pragma unroll
         for (int q = 0; q < 4; ++q) wv[q] = __builtin_nontemporal_load(tile + q * 64);
-        xw = xrow ? *reinterpret_cast<const uint64_t*>(xrow + (int64_t)blk_ * 8) : 0ull;
+#pragma unroll
+        for (int t = 0; t < T; ++t) xw[t] = xrow[t] ? *reinterpret_cast<const uint64_t*>(xrow[t] + (int64_t)blk_ * 8) : 0ull;
     };
     int blk = slot;
     // four blocks (16 KiB per wave) requested before the first is used (a rotating four-buffer pipeline, each buffer
     // refilled as soon as it is used, measured slower: 132 vs 118 us at 1M SNPs)
     for (; blk + 3 * nslots < nblk; blk += 4 * nslots) {
         f32x4 wv[4][4];
-        uint64_t xw[4];
+        uint64_t xw[4][T];
 #pragma unroll
         for (int u = 0; u < 4; ++u) request(wv[u], xw[u], blk + u * nslots);
 #pragma unroll
@@ -232,14 +252,16 @@ __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1,
     }
     for (; blk < nblk; blk += nslots) {
         f32x4 wv[4];
-        uint64_t xw;
+        uint64_t xw[T];
         request(wv, xw, blk);
         mma(wv, xw);
     }
     const int ldp = ngrp * WG_UNITS;
-    float* p = part + (int64_t)slot * (32 * ldp) + grp * WG_UNITS + w * 32 + c;
+    float* p = part + (int64_t)slot * (32 * T * ldp) + grp * WG_UNITS + w * 32 + c;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) p[PV_ROW(r, h) * ldp] = acc[r];
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[(32 * t + PV_ROW(r, h)) * ldp] = acc[t][r];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -613,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
     const int gw = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
-    const int bce_probs = st->bce_probs;
+    const int bce_probs = PV_BCE_MODE(st);
     const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
 
     PV_WT(0, 0);
@@ -664,19 +686,23 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
             }
         // (2) sigmoid / BCE-from-logits / dlogits ; reg r <-> sample b = ROW(r,h), lane <-> SNP l
         float dbias = 0.f;
+        auto sigmoid_bce = [&](auto Pc) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int b = PV_ROW(r, h);
-            const float x = 0.5f * pv_code(lo, hi, r);
-            const float z = a[r] + bias;
-            float bce, dz;
-            pv_bce(z, x, bce_probs, bce, dz);
-            const bool ok = lvalid && (b < nrows);
-            lossacc += ok ? bce : 0.f;
-            const float d = ok ? dz * inv_b : 0.f;
-            a[r] = d;
-            dbias += d;
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int b = PV_ROW(r, h);
+                const float x = 0.5f * pv_code(lo, hi, r);
+                const float z = a[r] + bias;
+                float bce, dz;
+                pv_bce<decltype(Pc)::value>(z, x, bce, dz);
+                const bool ok = lvalid && (b < nrows);
+                lossacc += ok ? bce : 0.f;
+                const float d = ok ? dz * inv_b : 0.f;
+                a[r] = d;
+                dbias += d;
+            }
+        };
+        if (bce_probs) sigmoid_bce(std::integral_constant<int, 1>{});
+        else sigmoid_bce(std::integral_constant<int, 0>{});
         if (TRAIN) {
             // bias: sum over the 32 samples = 16 regs + the other half-wave
             dbias += __shfl_xor(dbias, 32);
@@ -835,7 +861,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
     const int per = (bgroups + gridDim.x - 1) / gridDim.x;
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
-    const int bce_probs = st->bce_probs;
+    const int bce_probs = PV_BCE_MODE(st);
     const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
 
     // per SNP block of the workgroup: [0] partial logits posted, [1] partial logits read (both only ever grow)
@@ -906,19 +932,23 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
         const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
         // (2) sigmoid / BCE-from-logits / dlogits (every wave of the block computes the same values)
         float dbias = 0.f;
+        auto sigmoid_bce = [&](auto Pc) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int b = PV_ROW(r, h);
-            const float x = 0.5f * pv_code(lo, hi, r);
-            const float z = a[r] + bias;
-            float bce, dz;
-            pv_bce(z, x, bce_probs, bce, dz);
-            const bool ok = lvalid && (b < nrows);
-            lossacc += (ok && grp == 0) ? bce : 0.f;
-            const float d = ok ? dz * inv_b : 0.f;
-            a[r] = d;
-            dbias += d;
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int b = PV_ROW(r, h);
+                const float x = 0.5f * pv_code(lo, hi, r);
+                const float z = a[r] + bias;
+                float bce, dz;
+                pv_bce<decltype(Pc)::value>(z, x, bce, dz);
+                const bool ok = lvalid && (b < nrows);
+                lossacc += (ok && grp == 0) ? bce : 0.f;
+                const float d = ok ? dz * inv_b : 0.f;
+                a[r] = d;
+                dbias += d;
+            }
+        };
+        if (bce_probs) sigmoid_bce(std::integral_constant<int, 1>{});
+        else sigmoid_bce(std::integral_constant<int, 0>{});
         if (TRAIN) {
             dbias += __shfl_xor(dbias, 32);
             if (grp == 0 && h == 0 && lvalid) {
@@ -1047,34 +1077,42 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
 //   * each wave owns a block column of dg: the workgroup's partial tile needs no cross-wave sum when BPI == 1.
 // Waves of ONE SNP block meet at two LDS counters that only grow (pv_block_sync).  LDS: g tile + per wave 2 x [32][33].
 // ---------------------------------------------------------------------------------------------
-template <int NWB>
+// T = 32-row tiles of the device pass.  T > 1 (a batch above 32 rows in ONE weight pass, width 128 only): logits, sigmoid / BCE
+// and dg run per tile on the block the wave already holds, dV sums over the tiles, Adam runs once.  The g tiles of all T
+// tiles sit in LDS ([T][32][LDG]); the T accumulators of dg do not fit 256 registers next to the rest, so the register
+// budget is that of one workgroup per CU (512 per lane, the compiler parks what it has to in AGPRs) and the occupancy is
+// what the count comes to (two workgroups per CU at T = 2).
+template <int NWB, int T = 1>
 struct PvDec2 {
-    static constexpr int NW = NWB == 3 ? 3 : 4;  // waves per workgroup
-    static constexpr int BPI = NW / NWB;         // SNP blocks per workgroup iteration
+    static constexpr int NW = NWB == 3 ? 3 : 4;              // waves per workgroup
+    static constexpr int BPI = NW / NWB;                     // SNP blocks per workgroup iteration
+    static constexpr int MINB = (T > 1) ? 1 : 2;              // workgroups per CU the register budget is set for
     static constexpr int WP = NWB * 32, LDG = WP + 1;
-    static constexpr size_t lds() { return (size_t)(32 * LDG + NW * 2 * 32 * 33) * 4; }
+    static constexpr size_t lds() {
+        const size_t work = (size_t)T * 32 * LDG + (size_t)NW * 2 * 32 * 33;
+        const size_t red = BPI > 1 ? (size_t)NW * T * 1024 + NW : NW;  // epilogue: dg fragments + loss
+        return (work > red ? work : red) * 4;
+    }
 };
-template <int NWB>
-__global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float* __restrict__ V, const float* __restrict__ mV,
-                                                                    const float* __restrict__ vV, float* __restrict__ V2,
-                                                                    float* __restrict__ mV2, float* __restrict__ vV2,
-                                                                    float* __restrict__ cb, float* __restrict__ mC,
-                                                                    float* __restrict__ vC, const float* __restrict__ g,
-                                                                    const uint64_t* __restrict__ Xt, int nblk, int L,
-                                                                    const PvStep* st, PvAdam adam, float* __restrict__ dgpart,
-                                                                    float* __restrict__ losspart, int ts) {
-    using G = PvDec2<NWB>;
+template <int NWB, int T = 1>
+__global__ __launch_bounds__((PvDec2<NWB, T>::NW * 64), (PvDec2<NWB, T>::MINB)) void pvk_dec2(
+    const float* __restrict__ V, const float* __restrict__ mV, const float* __restrict__ vV, float* __restrict__ V2,
+    float* __restrict__ mV2, float* __restrict__ vV2, float* __restrict__ cb, float* __restrict__ mC, float* __restrict__ vC,
+    const float* __restrict__ g, const uint64_t* __restrict__ Xt, int nblk, int L, const PvStep* st, PvAdam adam,
+    float* __restrict__ dgpart, float* __restrict__ losspart, int ts) {
+    using G = PvDec2<NWB, T>;
     constexpr int NW = G::NW, BPI = G::BPI, WP = G::WP, LDG = G::LDG;
+    static_assert(T == 1 || NWB == 4, "several row tiles: width 128 only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* g_s = smem;  // [32][LDG]
+    float* g_s = smem;  // [T][32][LDG]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, h = lane >> 5;
-    float* vt = smem + 32 * LDG + wave * (2 * 32 * 33);  // [32][33]; also this wave's partial-logit mailbox ([4][64][4])
-    float* dt = vt + 32 * 33;                            // [32][33]
+    float* vt = smem + T * 32 * LDG + wave * (2 * 32 * 33);  // [32][33]; also this wave's partial-logit mailbox ([4][64][4])
+    float* dt = vt + 32 * 33;                                // [32][33]
     const int bsub = wave / NWB, w = wave - bsub * NWB;
-    const float* mb0 = smem + 32 * LDG + (bsub * NWB) * (2 * 32 * 33);  // mailbox of block column 0 of this SNP block
+    const float* mb0 = smem + T * 32 * LDG + (bsub * NWB) * (2 * 32 * 33);  // mailbox of block column 0 of this SNP block
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
-    const int bce_probs = st->bce_probs;
+    const int bce_probs = PV_BCE_MODE(st);
     __shared__ int blk_sync[BPI][2];  // [0] partial logits posted, [1] partial logits read (both only ever grow)
     if (tid < 2 * BPI) blk_sync[tid >> 1][tid & 1] = 0;
     bool sync_ok = true;
@@ -1085,33 +1123,41 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
     auto block_of = [&](int it) { return (it * (int)gridDim.x + (int)blockIdx.x) * BPI + bsub; };
     auto tile = [&](int blk_) { return (int64_t)blk_ * ts + w * 256 + lane; };
     f32x4 vv[4], vn[4];
-    uint64_t xw = 0, xw_n = 0;
+    uint64_t xw[T] = {}, xw_n[T] = {};
     float bias = 0.f, bias_n = 0.f;
     int blk = block_of(0);
     if (blk < nblk) {  // the first block travels while g is staged
         const f32x4* tV = reinterpret_cast<const f32x4*>(V) + tile(blk);
 #pragma unroll
         for (int q = 0; q < 4; ++q) vv[q] = __builtin_nontemporal_load(tV + q * 64);
-        xw = Xt[blk * 32 + c];
+#pragma unroll
+        for (int t = 0; t < T; ++t) xw[t] = Xt[((int64_t)t * nblk + blk) * 32 + c];
         bias = cb[blk * 32 + c];
     }
-    for (int i = tid; i < 32 * WP; i += NW * 64) g_s[(i / WP) * LDG + (i % WP)] = g[i];
+    for (int i = tid; i < T * 32 * WP; i += NW * 64) g_s[(i / WP) * LDG + (i % WP)] = g[i];
     __syncthreads();
     PV_WT(0, 1);
-    // this wave's 32 units of g, as the A operands of products (1) and (4): the same for every visit
-    float g1[16], g4[16];
+    // one tile: this wave's 32 units of g as the A operands of products (1) and (4) are the same for every visit and live in
+    // registers; several tiles: read from LDS where they are used
+    float g1[T == 1 ? 16 : 1], g4[T == 1 ? 16 : 1];
+    if constexpr (T == 1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        g1[r] = g_s[c * LDG + w * 32 + PV_ROW(r, h)];    // A[i=b][k=unit]
-        g4[r] = g_s[PV_ROW(r, h) * LDG + w * 32 + c];    // A[i=unit_loc][k=b]
+        for (int r = 0; r < 16; ++r) {
+            g1[r] = g_s[c * LDG + w * 32 + PV_ROW(r, h)];    // A[i=b][k=unit]
+            g4[r] = g_s[PV_ROW(r, h) * LDG + w * 32 + c];    // A[i=unit_loc][k=b]
+        }
     }
 
-    f32x16 dg;
+    f32x16 dg[T];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dg[r] = 0.f;
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dg[t][r] = 0.f;
     float lossacc = 0.f;  // only the batch total enters the loss (popvae.py:423)
 
     for (int it = 0; blk < nblk; ++it) {
+        // several tiles: keep the (loop-invariant) g operand reads inside the loop, hoisted they would cost 32 T registers
+        if (T > 1) asm volatile("" ::: "memory");
         const int nb = block_of(it + 1) < nblk ? block_of(it + 1) : blk;  // past the end: a harmless re-read
         const int l = blk * 32 + c;
         const bool lvalid = l < L;
@@ -1123,69 +1169,106 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
         float cm = 0.f, cv = 0.f;
         {
             bias_n = cb[nb * 32 + c];
-            xw_n = Xt[nb * 32 + c];
+#pragma unroll
+            for (int t = 0; t < T; ++t) xw_n[t] = Xt[((int64_t)t * nblk + nb) * 32 + c];
             if (w == 0 && h == 0 && lvalid) {
                 cm = mC[l];
                 cv = vC[l];
             }
-            const f32x4* tM = reinterpret_cast<const f32x4*>(mV) + tb;
-            const f32x4* tVv = reinterpret_cast<const f32x4*>(vV) + tb;
             const f32x4* tVn = reinterpret_cast<const f32x4*>(V) + tile(nb);
 #pragma unroll
             for (int q = 0; q < 4; ++q) vn[q] = __builtin_nontemporal_load(tVn + q * 64);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                mq[q] = __builtin_nontemporal_load(tM + q * 64);
-                vq[q] = __builtin_nontemporal_load(tVv + q * 64);
-            }
         }
-        const uint64_t xs = xw >> (8 * h);
-        const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
-
-        // (1) logits a[b][l] over this wave's 32 units: M = b, N = l, K = unit.  A = g[b][unit], B = V fragment register.
-        f32x16 a;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            a = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[r], vv[r >> 2][r & 3], a, 0, 0, 0);
-        }
-        if (NWB > 1) {
-            // the NWB waves of this SNP block meet; the other blocks of the workgroup run on
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 t4 = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
-                reinterpret_cast<f32x4*>(vt)[q * 64 + lane] = t4;
-            }
-            ++nsync;
-            sync_ok &= pv_block_sync(&blk_sync[bsub][0], NWB * nsync, lane);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 sum = reinterpret_cast<const f32x4*>(mb0)[q * 64 + lane];
-#pragma unroll
-                for (int w2 = 1; w2 < NWB; ++w2) sum += reinterpret_cast<const f32x4*>(mb0 + w2 * (2 * 32 * 33))[q * 64 + lane];
-                a[4 * q] = sum[0]; a[4 * q + 1] = sum[1]; a[4 * q + 2] = sum[2]; a[4 * q + 3] = sum[3];
-            }
-            // mailboxes double as the V^T staging tiles of product (3): nobody overwrites one before all have read it
-            sync_ok &= pv_block_sync(&blk_sync[bsub][1], NWB * nsync, lane);
-        }
-        // (2) sigmoid / BCE-from-logits / dlogits ; reg r <-> sample b = ROW(r,h), lane <-> SNP l (every wave of the block
-        //     computes the same values)
         float dbias = 0.f;
+        f32x16 dv;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int b = PV_ROW(r, h);
-            const float x = 0.5f * pv_code(lo, hi, r);
-            const float z = a[r] + bias;
-            float bce, dz;
-            pv_bce(z, x, bce_probs, bce, dz);
-            const bool ok = lvalid && (b < nrows);
-            lossacc += (ok && w == 0) ? bce : 0.f;
-            const float d = ok ? dz * inv_b : 0.f;
-            a[r] = d;
-            dbias += d;
+        for (int r = 0; r < 16; ++r) dv[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (t == T - 1) {  // the moments: requested a tile ahead of the Adam update (32 registers the other tiles need)
+                const f32x4* tM = reinterpret_cast<const f32x4*>(mV) + tb;
+                const f32x4* tVv = reinterpret_cast<const f32x4*>(vV) + tb;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    mq[q] = __builtin_nontemporal_load(tM + q * 64);
+                    vq[q] = __builtin_nontemporal_load(tVv + q * 64);
+                }
+            }
+            const float* gt = g_s + t * 32 * LDG + w * 32;  // tile t, this wave's 32 units
+            const uint64_t xs = xw[t] >> (8 * h);
+            const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
+            // (1) logits a[b][l] over this wave's 32 units: M = b, N = l, K = unit.  A = g[b][unit], B = V fragment register.
+            f32x16 a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ga = T == 1 ? g1[T == 1 ? r : 0] : gt[c * LDG + PV_ROW(r, h)];
+                a = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, vv[r >> 2][r & 3], a, 0, 0, 0);
+            }
+            if (NWB > 1) {
+                // the NWB waves of this SNP block meet; the other blocks of the workgroup run on
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 t4 = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+                    reinterpret_cast<f32x4*>(vt)[q * 64 + lane] = t4;
+                }
+                ++nsync;
+                sync_ok &= pv_block_sync(&blk_sync[bsub][0], NWB * nsync, lane);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 sum = reinterpret_cast<const f32x4*>(mb0)[q * 64 + lane];
+#pragma unroll
+                    for (int w2 = 1; w2 < NWB; ++w2) sum += reinterpret_cast<const f32x4*>(mb0 + w2 * (2 * 32 * 33))[q * 64 + lane];
+                    a[4 * q] = sum[0]; a[4 * q + 1] = sum[1]; a[4 * q + 2] = sum[2]; a[4 * q + 3] = sum[3];
+                }
+                // mailboxes double as the V^T staging tiles of product (3): nobody overwrites one before all have read it
+                sync_ok &= pv_block_sync(&blk_sync[bsub][1], NWB * nsync, lane);
+            }
+            // (2) sigmoid / BCE / dlogits ; reg r <-> sample b = 32 t + ROW(r,h), lane <-> SNP l (every wave of the block
+            //     computes the same values)
+            auto sigmoid_bce = [&](auto Pc) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int b = 32 * t + PV_ROW(r, h);
+                    const float x = 0.5f * pv_code(lo, hi, r);
+                    const float z = a[r] + bias;
+                    float bce, dz;
+                    pv_bce<decltype(Pc)::value>(z, x, bce, dz);
+                    const bool ok = lvalid && (b < nrows);
+                    lossacc += (ok && w == 0) ? bce : 0.f;
+                    const float d = ok ? dz * inv_b : 0.f;
+                    a[r] = d;
+                    dbias += d;
+                }
+            };
+            if (bce_probs) sigmoid_bce(std::integral_constant<int, 1>{});
+            else sigmoid_bce(std::integral_constant<int, 0>{});
+            // (3) dg[b][unit] += sum_l da[b][l] * V[unit][l] : M = b, N = unit, K = l.  A needs da^T, B needs V^T (unit on
+            //     the lane): both staged through this wave's LDS tiles.
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dt[PV_ROW(r, h) * 33 + c] = a[r];                 // [b][l_loc]
+                vt[PV_ROW(r, h) * 33 + c] = vv[r >> 2][r & 3];    // [unit_loc][l_loc]
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float av = dt[c * 33 + PV_ROW(r, h)];  // A[i=b][k=l]
+                const float bv = vt[c * 33 + PV_ROW(r, h)];  // B[k=l][j=unit_loc]
+                dg[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, dg[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            // (4) dV[unit][l] += sum_b g[b][unit] * da[b][l] : M = unit, N = l, K = b (summed over the tiles)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ga = T == 1 ? g4[T == 1 ? r : 0] : gt[PV_ROW(r, h) * LDG + c];  // A[i=unit_loc][k=b]
+                dv = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, a[r], dv, 0, 0, 0);
+            }
         }
-        // bias: sum over the 32 samples = 16 regs + the other half-wave; block column 0 updates it
+        // bias: sum over the samples = registers + the other half-wave; block column 0 updates it
         dbias += __shfl_xor(dbias, 32);
         if (w == 0 && h == 0 && lvalid) {
             float w_ = bias;
@@ -1194,31 +1277,7 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
             mC[l] = cm;
             vC[l] = cv;
         }
-        // (3) dg[b][unit] += sum_l da[b][l] * V[unit][l] : M = b, N = unit, K = l.  A needs da^T, B needs V^T (unit on the
-        //     lane): both staged through this wave's LDS tiles.
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dt[PV_ROW(r, h) * 33 + c] = a[r];                 // [b][l_loc]
-            vt[PV_ROW(r, h) * 33 + c] = vv[r >> 2][r & 3];    // [unit_loc][l_loc]
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float av = dt[c * 33 + PV_ROW(r, h)];  // A[i=b][k=l]
-            const float bv = vt[c * 33 + PV_ROW(r, h)];  // B[k=l][j=unit_loc]
-            dg = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, dg, 0, 0, 0);
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        // (4) dV[unit][l] = sum_b g[b][unit] * da[b][l] : M = unit, N = l, K = b ; then Adam on the block
-        f32x16 dv;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dv[r] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dv = __builtin_amdgcn_mfma_f32_32x32x2f32(g4[r], a[r], dv, 0, 0, 0);
-        }
+        // Adam on the block
         f32x4* oV = reinterpret_cast<f32x4*>(V2) + tb;
         f32x4* oM = reinterpret_cast<f32x4*>(mV2) + tb;
         f32x4* oVv = reinterpret_cast<f32x4*>(vV2) + tb;
@@ -1240,14 +1299,15 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) vv[q] = vn[q];
-        xw = xw_n;
+#pragma unroll
+        for (int t = 0; t < T; ++t) xw[t] = xw_n[t];
         bias = bias_n;
         blk = block_of(it + 1);
     }
     // ---- per-workgroup reductions (fixed order) ----
     __syncthreads();  // everyone done with g_s / the staging tiles
     PV_WT(0, 2);
-    float* red = smem;  // [NW][16][64] for dg when BPI > 1, then [NW] loss
+    float* red = smem;  // [NW][T][16][64] for dg when BPI > 1, then [NW] loss
     lossacc += __shfl_xor(lossacc, 1);
     lossacc += __shfl_xor(lossacc, 2);
     lossacc += __shfl_xor(lossacc, 4);
@@ -1255,11 +1315,13 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
     lossacc += __shfl_xor(lossacc, 16);
     lossacc += __shfl_xor(lossacc, 32);
     if (!sync_ok) lossacc = __builtin_nanf("");  // a sync point gave up: make the step loudly wrong
-    float* lred = red + NW * 1024;
+    float* lred = red + (BPI > 1 ? NW * T * 1024 : 0);
     if (lane == 0) lred[wave] = lossacc;
     if (BPI > 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = dg[r];
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave * T + t) * 16 + r) * 64 + lane] = dg[t][r];
     }
     __syncthreads();
     if (tid == 0) {
@@ -1267,19 +1329,21 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
         for (int w2 = 0; w2 < NW; ++w2) sacc += lred[w2];
         losspart[blockIdx.x] = sacc;
     }
-    float* dgp = dgpart + (int64_t)blockIdx.x * (32 * WP);
+    float* dgp = dgpart + (int64_t)blockIdx.x * (32 * T * WP);  // [32 T][WP]
     if (BPI > 1) {
-        for (int e = tid; e < NWB * 1024; e += NW * 64) {
-            const int wq = e >> 10, f = e & 1023;  // block column, fragment element
-            float sum = red[wq * 1024 + f];
+        for (int e = tid; e < NWB * T * 1024; e += NW * 64) {
+            const int wq = e / (T * 1024), f = e % (T * 1024);  // block column, (tile, fragment element)
+            float sum = red[wq * (T * 1024) + f];
 #pragma unroll
-            for (int b2 = 1; b2 < BPI; ++b2) sum += red[(b2 * NWB + wq) * 1024 + f];
-            const int r = f >> 6, ln = f & 63;
-            dgp[PV_ROW(r, ln >> 5) * WP + wq * 32 + (ln & 31)] = sum;
+            for (int b2 = 1; b2 < BPI; ++b2) sum += red[(b2 * NWB + wq) * (T * 1024) + f];
+            const int t = f >> 10, r = (f >> 6) & 15, ln = f & 63;
+            dgp[(32 * t + PV_ROW(r, ln >> 5)) * WP + wq * 32 + (ln & 31)] = sum;
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dgp[PV_ROW(r, h) * WP + w * 32 + c] = dg[r];
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dgp[(32 * t + PV_ROW(r, h)) * WP + w * 32 + c] = dg[t][r];
     }
     PV_WT(0, 3);
 }
@@ -1360,7 +1424,7 @@ __global__ void pvk_loss_final(const float* __restrict__ recon, const float* __r
 struct PvBwdOp;
 template <int MODE>
 __device__ __forceinline__ void pvn_adam_unit(const PvBwdOp* __restrict__ ops, int bx, int by, int lane_,
-                                              const PvStep* __restrict__ st, PvAdam adam);
+                                              const PvStep* __restrict__ st, PvAdam adam, int ntiles);
 // Training pass of pvk_enc_bwd (MODE_TRAIN), block-column-major: the waves of a unit group are numbered gw = 0, 1, ...;
 // wave gw owns block column w = gw % NWB (32 units) of the subtiles slot, slot + nslots, ... (slot = gw / NWB), so
 //   * the unit of work is a 32 x 32 block (12 KiB of W | m | v per wave) instead of a whole subtile: a workgroup's share of a
@@ -1375,7 +1439,9 @@ __device__ __forceinline__ void pvn_adam_unit(const PvBwdOp* __restrict__ ops, i
 // The narrow layers' weight-gradient + Adam units (adam_units > 0) take the first ceil(adam_units / 4) workgroups of the
 // launch, one unit per wave, and exit: carried by sweep waves they delayed those by 10-30 us (their dependent loads crawl
 // while the chip streams), which was the tail of the kernel at small shapes.
-template <int NWB, int FUSE>
+// T = 32-row tiles of the device pass: dpre is [32 T][ldp], Xt holds T word arrays of nblk * 32 entries one after the other, and
+// dW sums over the tiles before the ONE Adam update (a batch above 32 rows in one weight pass; the fused forward needs T == 1).
+template <int NWB, int FUSE, int T>
 __device__ __forceinline__ void pv_enc_bwd_train(const float* __restrict__ W1, const float* __restrict__ mW,
                                                  const float* __restrict__ vW, float* __restrict__ W1o, float* __restrict__ mWo,
                                                  float* __restrict__ vWo, const float* __restrict__ dpre, int ldp,
@@ -1384,13 +1450,14 @@ __device__ __forceinline__ void pv_enc_bwd_train(const float* __restrict__ W1, c
                                                  int next_off, int next_n, float* __restrict__ fpart, int ts,
                                                  const PvBwdOp* __restrict__ adam_ops, int adam_units, float* smem) {
     constexpr int WG_UNITS = NWB * 32;
+    static_assert(T == 1 || FUSE == 0, "the fused forward rides on one-tile passes only");
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, h = lane >> 5;
     int bx = blockIdx.x, nwg = gridDim.x;
     if (adam_ops) {
         const int awgs = (adam_units + 3) >> 2;
         if (bx < awgs) {
             const int unit = bx * 4 + wave;
-            if (unit < adam_units) pvn_adam_unit<PV_MODE_TRAIN>(adam_ops, unit & 15, unit >> 4, lane, st, adam);
+            if (unit < adam_units) pvn_adam_unit<PV_MODE_TRAIN>(adam_ops, unit & 15, unit >> 4, lane, st, adam, T);
             return;
         }
         bx -= awgs;
@@ -1416,34 +1483,35 @@ __device__ __forceinline__ void pv_enc_bwd_train(const float* __restrict__ W1, c
     };
     const uint8_t* nrow = nullptr;  // FUSE: lane c's sample of the next batch
     if (FUSE && c < next_n) nrow = geno + (int64_t)rows[next_off + c] * row_bytes;
-    auto words = [&](int blk_, uint64_t& xw_, uint64_t& xn_) {
-        xw_ = Xt[blk_ * 32 + c];
+    auto words = [&](int blk_, uint64_t (&xw_)[T], uint64_t& xn_) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) xw_[t] = Xt[((int64_t)t * nblk + blk_) * 32 + c];
         if (FUSE) xn_ = nrow ? *reinterpret_cast<const uint64_t*>(nrow + (int64_t)blk_ * 8) : 0ull;
     };
     Block bk[2];
-    uint64_t xw = 0, xn = 0;
+    uint64_t xw[T] = {}, xn = 0;
     int blk = slot;
     if (blk < nblk) {  // the first block travels while dpre is staged
         request(bk[0], blk);
         words(blk, xw, xn);
     }
-    for (int i = tid; i < 32 * ldp; i += 256) {
+    for (int i = tid; i < 32 * T * ldp; i += 256) {
         const int b = i / ldp, u = i % ldp;
-        smem[((u / WG_UNITS) * 32 + b) * WG_UNITS + (u % WG_UNITS)] = dpre[i];
+        smem[((u / WG_UNITS) * (32 * T) + b) * WG_UNITS + (u % WG_UNITS)] = dpre[i];
     }
     __syncthreads();
     PV_WT(1, 1);
-    const float* dp = smem + grp * 32 * WG_UNITS + w * 32;
+    const float* dp = smem + grp * (32 * T) * WG_UNITS + w * 32;
     f32x16 facc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) facc[r] = 0.f;
     auto block = [&](Block& cur, Block& nxt) {
         const int nb = blk + nslots < nblk ? blk + nslots : blk;  // past the end: a harmless re-read of this block
         request(nxt, nb);
-        uint64_t xw2 = 0, xn2 = 0;
+        uint64_t xw2[T], xn2 = 0;
         words(nb, xw2, xn2);
-        const uint64_t xs = xw >> (8 * h), ns = xn >> (8 * h);
-        const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32), nlo = (uint32_t)ns, nhi = (uint32_t)(ns >> 32);
+        const uint64_t ns = xn >> (8 * h);
+        const uint32_t nlo = (uint32_t)ns, nhi = (uint32_t)(ns >> 32);
         const int64_t o = ((int64_t)blk * ngrp + grp) * ts + w * 256 + lane;
         f32x4* oW = reinterpret_cast<f32x4*>(W1o) + o;
         f32x4* oM = reinterpret_cast<f32x4*>(mWo) + o;
@@ -1452,9 +1520,14 @@ __device__ __forceinline__ void pv_enc_bwd_train(const float* __restrict__ W1, c
 #pragma unroll
         for (int r = 0; r < 16; ++r) dw[r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float bv = dp[PV_ROW(r, h) * WG_UNITS + c];  // B[k=b][j=unit]
-            dw = __builtin_amdgcn_mfma_f32_32x32x2f32(pv_code(lo, hi, r), bv, dw, 0, 0, 0);
+        for (int t = 0; t < T; ++t) {
+            const uint64_t xs = xw[t] >> (8 * h);
+            const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bv = dp[(32 * t + PV_ROW(r, h)) * WG_UNITS + c];  // B[k=b][j=unit]
+                dw = __builtin_amdgcn_mfma_f32_32x32x2f32(pv_code(lo, hi, r), bv, dw, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1477,7 +1550,8 @@ __device__ __forceinline__ void pv_enc_bwd_train(const float* __restrict__ W1, c
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // the next block's requests stay ahead of this block's work, one block deep
-        xw = xw2;
+#pragma unroll
+        for (int t = 0; t < T; ++t) xw[t] = xw2[t];
         xn = xn2;
         blk += nslots;
     };
@@ -1496,7 +1570,7 @@ __device__ __forceinline__ void pv_enc_bwd_train(const float* __restrict__ W1, c
     }
 }
 
-template <int NWB, int MODE, int FUSE>
+template <int NWB, int MODE, int FUSE, int T = 1>
 __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ W1, const float* __restrict__ mW,
                                                    const float* __restrict__ vW, float* __restrict__ W1o,
                                                    float* __restrict__ mWo, float* __restrict__ vWo,
@@ -1511,14 +1585,14 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
     PV_WT(1, 0);
     if constexpr (MODE == PV_MODE_TRAIN) {
-        pv_enc_bwd_train<NWB, FUSE>(W1, mW, vW, W1o, mWo, vWo, dpre, ldp, Xt, nblk, ngrp, st, adam, geno, row_bytes, rows, next_off,
+        pv_enc_bwd_train<NWB, FUSE, T>(W1, mW, vW, W1o, mWo, vWo, dpre, ldp, Xt, nblk, ngrp, st, adam, geno, row_bytes, rows, next_off,
                                     next_n, fpart, ts, adam_ops, adam_units, smem);
         PV_WT(1, 3);
         return;
     }
     // Gradient dump (MODE_GRAD) and Adam on this pass + the dump (MODE_TRAIN_ACC): tiles of a batch above 32 rows.  One
     // wave per subtile, round-robin; a workgroup stays on one unit group (gridDim.x is a multiple of ngrp).
-    static_assert(MODE == PV_MODE_TRAIN || FUSE == 0, "the fused forward rides on the plain training pass only");
+    static_assert(MODE == PV_MODE_TRAIN || (FUSE == 0 && T == 1), "fused forward / several row tiles: plain training pass only");
     const int grp = blockIdx.x % ngrp;
     const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / ngrp) * 4 + wave), nslots = (gridDim.x / ngrp) * 4;
     const float alpha = st->alpha;

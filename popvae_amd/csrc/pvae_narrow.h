@@ -229,7 +229,8 @@ __device__ __forceinline__ void pvn_lds_barrier() {
 __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __restrict__ ops, int op0, int nops,
                                                               const float* __restrict__ P,
                                                               const float* __restrict__ eps, int K, int Kz,
-                                                              float* __restrict__ z_out, float* __restrict__ kl_out) {
+                                                              float* __restrict__ z_out, float* __restrict__ kl_out,
+                                                              int nworkers) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cur = smem;                   // [PVN_ROWS][PVN_LD] of the [32][PVN_LD] reserved
     float* nxt = smem + 32 * PVN_LD;
@@ -237,10 +238,12 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, q = lane >> 4;
     const int n0 = wave * 16;
     const int rb = PVN_ROWS * (int)blockIdx.x;  // first batch row of this worker
-    if (blockIdx.x >= PVN_WORKERS) {
+    // nworkers = 2 per 32-row tile of the device pass (1 tile, or up to 4 for a batch above 32 rows in one weight pass);
+    // at most 8, so that the workers are the first eight workgroups: one per die
+    if ((int)blockIdx.x >= nworkers) {
         // warm-up role: block 8 (p + 1) + w shares (by the dispatcher's round-robin placement) the XCD of worker w
         const int p = (int)(blockIdx.x >> 3) - 1;
-        if ((int)(blockIdx.x & 7) < PVN_WORKERS && p >= 0 && p < nops) {
+        if (blockIdx.x >= 8 && (int)(blockIdx.x & 7) < nworkers && p >= 0 && p < nops) {
             const PvFwdOp op = ops[p];
             if (op.kind == PVN_DENSE) pvn_warm_l2(op.W, op.kin * op.nout, tid);
         }
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                                                               const float* __restrict__ eps,
                                                               const float* __restrict__ heads, int Kh, int K,
                                                               const PvStep* __restrict__ st, PvAdam adam,
-                                                              float* __restrict__ out3, int update) {
+                                                              float* __restrict__ out3, int update, int nworkers) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cur = smem;
     float* nxt = smem + 32 * PVN_LD;
@@ -373,9 +376,9 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, q = lane >> 4;
     const int n0 = wave * 16;
     const int rb = PVN_ROWS * (int)blockIdx.x;  // first batch row of this worker
-    if (blockIdx.x >= PVN_WORKERS) {
+    if ((int)blockIdx.x >= nworkers) {
         const int p = (int)(blockIdx.x >> 3) - 1;
-        if (update && (int)(blockIdx.x & 7) < PVN_WORKERS && p >= 0 && p < nops) {
+        if (update && blockIdx.x >= 8 && (int)(blockIdx.x & 7) < nworkers && p >= 0 && p < nops) {
             const PvBwdOp op = ops[p];
             if (op.kind == PVN_DENSE) pvn_warm_l2(op.Wb, op.kin * op.nout, tid);
             if (op.kind != PVN_REPARAM && op.act == PV_ACT_ELU) pvn_warm_l2(op.Y, 32 * op.nout, tid);
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     const float inv_b = st->inv_b;
 
     if (blockIdx.x == 0 && tid == 0) {  // loss = mean_b(recon + kl) (popvae.py:423)
-        float sr = xch[32 * W0], sk = 0.f;
+        float sr = xch[16 * nworkers * W0], sk = 0.f;  // the recon sum sits behind the rows of the pass
         for (int b = 0; b < nrows; ++b) sk += kl[b];
         out3[0] = (sr + sk) * inv_b;
         out3[1] = sr * inv_b;
@@ -529,9 +532,10 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
 // ---------------------------------------------------------------------------------------------
 // One unit of that work = one wave: (bx, by) = (32x32 block index within the layer, op index); as a device function so
 // that the wide encoder backward can carry the units on its first workgroups (pvk_enc_bwd) instead of a launch of its own.
+// ntiles: 32-row tiles of the device pass (the batch sum runs over all of them)
 template <int MODE>
 __device__ __forceinline__ void pvn_adam_unit(const PvBwdOp* __restrict__ ops, int bx, int by, int lane_,
-                                              const PvStep* __restrict__ st, PvAdam adam) {
+                                              const PvStep* __restrict__ st, PvAdam adam, int ntiles) {
     const PvBwdOp op = ops[by];
     if (op.kind == PVN_FIRST_BIAS) {
         // bias of the first (wide) layer: column sums of dpre1 over the batch, 64 columns per block.  kin != 0 marks
@@ -540,7 +544,7 @@ __device__ __forceinline__ void pvn_adam_unit(const PvBwdOp* __restrict__ ops, i
         if (!op.kin || n >= op.nout) return;
         float g = 0.f;
 #pragma unroll 8
-        for (int b = 0; b < 32; ++b) g += op.dpre[b * op.nout + n];
+        for (int b = 0; b < 32 * ntiles; ++b) g += op.dpre[b * op.nout + n];
         if (MODE == PV_MODE_GRAD) {
             op.mB[n] = st->acc ? op.mB[n] + g : g;
         } else {
@@ -571,17 +575,19 @@ __device__ __forceinline__ void pvn_adam_unit(const PvBwdOp* __restrict__ ops, i
             vv[r] = (op.vW + ro)[voff];
         }
     }
-    float a[16], b[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        a[s] = op.in[(2 * s + h) * Kin + kb * 32 + c];    // A[i = k][kk = b]
-        b[s] = op.dpre[(2 * s + h) * N + nb * 32 + c];    // B[kk = b][j = n]
-    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int t = 0; t < ntiles; ++t) {
+        float a[16], b[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+        for (int s = 0; s < 16; ++s) {
+            a[s] = op.in[(32 * t + 2 * s + h) * Kin + kb * 32 + c];    // A[i = k][kk = b]
+            b[s] = op.dpre[(32 * t + 2 * s + h) * N + nb * 32 + c];    // B[kk = b][j = n]
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int ro = ((r & 3) + 8 * (r >> 2)) * N;
@@ -603,8 +609,8 @@ __device__ __forceinline__ void pvn_adam_unit(const PvBwdOp* __restrict__ ops, i
     if (kb == 0 && h == 0) {  // bias of these 32 columns: column sums of dpre
         const int n = nb * 32 + c;
         float g = 0.f;
-#pragma unroll
-        for (int s = 0; s < 32; ++s) g += op.dpre[s * N + n];
+#pragma unroll 8
+        for (int s = 0; s < 32 * ntiles; ++s) g += op.dpre[s * N + n];
         if (MODE == PV_MODE_GRAD) {
             op.mB[n] = st->acc ? op.mB[n] + g : g;
         } else {
@@ -621,7 +627,7 @@ __device__ __forceinline__ void pvn_adam_unit(const PvBwdOp* __restrict__ ops, i
 template <int MODE>
 __global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict__ ops, const PvStep* __restrict__ st,
                                                       PvAdam adam) {
-    pvn_adam_unit<MODE>(ops, blockIdx.x, blockIdx.y, threadIdx.x, st, adam);
+    pvn_adam_unit<MODE>(ops, blockIdx.x, blockIdx.y, threadIdx.x, st, adam, 1);
 }
 
 // Per-layer path (widths above 128): the narrow layers' dW + Adam units and, as one more row of the grid, the wide first
@@ -640,7 +646,7 @@ __global__ __launch_bounds__(64) void pvk_narrow_adam_bias(const PvBwdOp* __rest
         else pv_bias_bwd_block<MODE>(Y, dY, N, act, dpre, bias, mB, vB, st, adam, gB, blockIdx.x);  // blocks beyond N return
         return;
     }
-    if ((int)blockIdx.x < adam_x) pvn_adam_unit<MODE>(ops, blockIdx.x, blockIdx.y, threadIdx.x, st, adam);
+    if ((int)blockIdx.x < adam_x) pvn_adam_unit<MODE>(ops, blockIdx.x, blockIdx.y, threadIdx.x, st, adam, 1);
 }
 
 // Rebuilds the operand-order copies from the Keras-layout kernels (after set_weights / init / restore).  grid = (16, n_ops),
