@@ -103,10 +103,10 @@ struct pvae_engine {
     float* h_out3 = nullptr;       // pinned staging of {loss, recon, kl}
     int enc_wgs = 0, dec_wgs = 0, encb_wgs = 0, dec_eval_wgs = 0;
     int dec2_wgs = 0;          // plain training pass at widths up to 128: pvk_dec2 (0 = use pvk_dec)
-    // Batches of 33 .. 128 rows in ONE weight pass (width 128, one rank): T = 2 or 4 row tiles of 32 go through the wide
-    // kernels' <.., T> instantiations and 2 T chain workers; activation buffers hold 32 T rows.  T == 1: off.
+    // Batches of 33 .. 128 rows in ONE weight pass (width 128, one rank): T = 2 or 4 row tiles of 32 go through pvk_enc_fwd /
+    // pvk_enc_bwd <.., T>, pvk_dec3<T> and 2 T chain workers; activation buffers hold 32 T rows.  T == 1: off.
     int T = 1;
-    int dec2t_wgs = 0;         // grid of pvk_dec2<4, T> (one 8-wave workgroup per CU)
+    int dec3_wgs = 0;          // grid of pvk_dec3<T> (one workgroup per CU, 4 / T subtiles per iteration)
     int encb_parts = 0;        // partial tiles [32][Wp] the fused forward of pvk_enc_bwd leaves in encpart (one per subtile slot)
     int64_t encpart_floats = 0;
     int64_t tile_floats = 0;
@@ -327,10 +327,10 @@ int setup_kernel_attrs(pvae_engine* e) {
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_GRAD, 0>), lds_enc_bwd(e->Wp)));         \
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN_ACC, 0>), lds_enc_bwd(e->Wp)));
     if (e->T == 2) {
-        HIPCHK(allow_lds((pvk_dec2<4, 2>), (PvDec2<4, 2>::lds())));
+        HIPCHK(allow_lds(pvk_dec3<2>, PvDec3<2>::lds()));
         HIPCHK(allow_lds((pvk_enc_bwd<4, PV_MODE_TRAIN, 0, 2>), 2 * lds_enc_bwd(e->Wp)));
     } else if (e->T == 4) {
-        HIPCHK(allow_lds((pvk_dec2<4, 4>), (PvDec2<4, 4>::lds())));
+        HIPCHK(allow_lds(pvk_dec3<4>, PvDec3<4>::lds()));
         HIPCHK(allow_lds((pvk_enc_bwd<4, PV_MODE_TRAIN, 0, 4>), 4 * lds_enc_bwd(e->Wp)));
     }
     switch (e->NWB) {
@@ -888,12 +888,13 @@ int multi_tile_launches(pvae_engine* e, int row_offset, float* d_out3) {
     }
     {
         Timer t(e, C_DEC);
-        hipLaunchKernelGGL((pvk_dec2<4, T>), dim3(e->dec2t_wgs), dim3(PvDec2<4, T>::NW * 64), (PvDec2<4, T>::lds()), e->stream,
+        const int wgs = e->dec3_wgs;
+        hipLaunchKernelGGL(pvk_dec3<T>, dim3(wgs), dim3(256), PvDec3<T>::lds(), e->stream,
                            (const float*)e->Vout.w, (const float*)e->Vout.m, (const float*)e->Vout.v, e->Vout.w2, e->Vout.m2, e->Vout.v2,
                            e->cout.w, e->cout.m, e->cout.v, (const float*)e->g[e->D - 1], (const uint64_t*)e->Xt, e->nblk, (int)e->L,
                            (const PvStep*)e->st, e->adam, e->dgpart, e->losspart, e->ts4);
         e->Vout.swap();
-        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(nR)), dim3(256), 0, e->stream, e->dgpart, e->dec2t_wgs, nR, 1.0f,
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(nR)), dim3(256), 0, e->stream, e->dgpart, wgs, nR, 1.0f,
                            e->xch1, e->losspart, e->xch1 + nR);
         if ((rc = launch_check(e, "dec"))) return rc;
     }
@@ -1257,14 +1258,14 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     if (e->T > 1) {
         hipDeviceProp_t prop2;
         HK(hipGetDeviceProperties(&prop2, e->dev));
-        int occ = 1;
-        if (e->T == 2) HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (pvk_dec2<4, 2>), 256, (PvDec2<4, 2>::lds())));
-        else HK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (pvk_dec2<4, 4>), 256, (PvDec2<4, 4>::lds())));
-        e->dec2t_wgs = std::max(1, std::min((prop2.multiProcessorCount > 0 ? prop2.multiProcessorCount : 256) * std::max(occ, 1), e->nblk));
+        const int cus2 = prop2.multiProcessorCount > 0 ? prop2.multiProcessorCount : 256;
+        const int spw = 4 / e->T;
+        e->dec3_wgs = std::max(1, std::min(cus2, (e->nblk + spw - 1) / spw));
     }
     e->fuse_fwd = !getenv("PVAE_NO_FUSE_FWD");
-    CK(allocf(e, &e->dgpart, std::max((int64_t)std::max(e->dec_wgs, e->dec2_wgs) * 32 * e->Wp, (int64_t)e->dec2t_wgs * 32 * e->T * e->Wp)));
-    CK(allocf(e, &e->losspart, (int64_t)std::max(std::max(std::max(e->dec_wgs, e->dec2_wgs), e->dec_eval_wgs), e->dec2t_wgs)));
+    CK(allocf(e, &e->dgpart, std::max((int64_t)std::max(e->dec_wgs, e->dec2_wgs) * 32 * e->Wp,
+                                      (int64_t)e->dec3_wgs * 32 * e->T * e->Wp)));
+    CK(allocf(e, &e->losspart, (int64_t)std::max(std::max(std::max(e->dec_wgs, e->dec2_wgs), e->dec_eval_wgs), e->dec3_wgs)));
 
     HK(hipMalloc(&e->st, sizeof(PvStep)));
     PvStep st0{};

@@ -1077,39 +1077,31 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
 //   * each wave owns a block column of dg: the workgroup's partial tile needs no cross-wave sum when BPI == 1.
 // Waves of ONE SNP block meet at two LDS counters that only grow (pv_block_sync).  LDS: g tile + per wave 2 x [32][33].
 // ---------------------------------------------------------------------------------------------
-// T = 32-row tiles of the device pass.  T > 1 (a batch above 32 rows in ONE weight pass, width 128 only): logits, sigmoid / BCE
-// and dg run per tile on the block the wave already holds, dV sums over the tiles, Adam runs once.  The g tiles of all T
-// tiles sit in LDS ([T][32][LDG]); the T accumulators of dg do not fit 256 registers next to the rest, so the register
-// budget is that of one workgroup per CU (512 per lane, the compiler parks what it has to in AGPRs) and the occupancy is
-// what the count comes to (two workgroups per CU at T = 2).
-template <int NWB, int T = 1>
+template <int NWB>
 struct PvDec2 {
-    static constexpr int NW = NWB == 3 ? 3 : 4;              // waves per workgroup
-    static constexpr int BPI = NW / NWB;                     // SNP blocks per workgroup iteration
-    static constexpr int MINB = (T > 1) ? 1 : 2;              // workgroups per CU the register budget is set for
+    static constexpr int NW = NWB == 3 ? 3 : 4;  // waves per workgroup
+    static constexpr int BPI = NW / NWB;         // SNP blocks per workgroup iteration
     static constexpr int WP = NWB * 32, LDG = WP + 1;
-    static constexpr size_t lds() {
-        const size_t work = (size_t)T * 32 * LDG + (size_t)NW * 2 * 32 * 33;
-        const size_t red = BPI > 1 ? (size_t)NW * T * 1024 + NW : NW;  // epilogue: dg fragments + loss
-        return (work > red ? work : red) * 4;
-    }
+    static constexpr size_t lds() { return (size_t)(32 * LDG + NW * 2 * 32 * 33) * 4; }
 };
-template <int NWB, int T = 1>
-__global__ __launch_bounds__((PvDec2<NWB, T>::NW * 64), (PvDec2<NWB, T>::MINB)) void pvk_dec2(
-    const float* __restrict__ V, const float* __restrict__ mV, const float* __restrict__ vV, float* __restrict__ V2,
-    float* __restrict__ mV2, float* __restrict__ vV2, float* __restrict__ cb, float* __restrict__ mC, float* __restrict__ vC,
-    const float* __restrict__ g, const uint64_t* __restrict__ Xt, int nblk, int L, const PvStep* st, PvAdam adam,
-    float* __restrict__ dgpart, float* __restrict__ losspart, int ts) {
-    using G = PvDec2<NWB, T>;
+template <int NWB>
+__global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float* __restrict__ V, const float* __restrict__ mV,
+                                                                    const float* __restrict__ vV, float* __restrict__ V2,
+                                                                    float* __restrict__ mV2, float* __restrict__ vV2,
+                                                                    float* __restrict__ cb, float* __restrict__ mC,
+                                                                    float* __restrict__ vC, const float* __restrict__ g,
+                                                                    const uint64_t* __restrict__ Xt, int nblk, int L,
+                                                                    const PvStep* st, PvAdam adam, float* __restrict__ dgpart,
+                                                                    float* __restrict__ losspart, int ts) {
+    using G = PvDec2<NWB>;
     constexpr int NW = G::NW, BPI = G::BPI, WP = G::WP, LDG = G::LDG;
-    static_assert(T == 1 || NWB == 4, "several row tiles: width 128 only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* g_s = smem;  // [T][32][LDG]
+    float* g_s = smem;  // [32][LDG]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, h = lane >> 5;
-    float* vt = smem + T * 32 * LDG + wave * (2 * 32 * 33);  // [32][33]; also this wave's partial-logit mailbox ([4][64][4])
-    float* dt = vt + 32 * 33;                                // [32][33]
+    float* vt = smem + 32 * LDG + wave * (2 * 32 * 33);  // [32][33]; also this wave's partial-logit mailbox ([4][64][4])
+    float* dt = vt + 32 * 33;                            // [32][33]
     const int bsub = wave / NWB, w = wave - bsub * NWB;
-    const float* mb0 = smem + T * 32 * LDG + (bsub * NWB) * (2 * 32 * 33);  // mailbox of block column 0 of this SNP block
+    const float* mb0 = smem + 32 * LDG + (bsub * NWB) * (2 * 32 * 33);  // mailbox of block column 0 of this SNP block
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
     const int bce_probs = PV_BCE_MODE(st);
@@ -1123,41 +1115,33 @@ __global__ __launch_bounds__((PvDec2<NWB, T>::NW * 64), (PvDec2<NWB, T>::MINB)) 
     auto block_of = [&](int it) { return (it * (int)gridDim.x + (int)blockIdx.x) * BPI + bsub; };
     auto tile = [&](int blk_) { return (int64_t)blk_ * ts + w * 256 + lane; };
     f32x4 vv[4], vn[4];
-    uint64_t xw[T] = {}, xw_n[T] = {};
+    uint64_t xw = 0, xw_n = 0;
     float bias = 0.f, bias_n = 0.f;
     int blk = block_of(0);
     if (blk < nblk) {  // the first block travels while g is staged
         const f32x4* tV = reinterpret_cast<const f32x4*>(V) + tile(blk);
 #pragma unroll
         for (int q = 0; q < 4; ++q) vv[q] = __builtin_nontemporal_load(tV + q * 64);
-#pragma unroll
-        for (int t = 0; t < T; ++t) xw[t] = Xt[((int64_t)t * nblk + blk) * 32 + c];
+        xw = Xt[blk * 32 + c];
         bias = cb[blk * 32 + c];
     }
-    for (int i = tid; i < T * 32 * WP; i += NW * 64) g_s[(i / WP) * LDG + (i % WP)] = g[i];
+    for (int i = tid; i < 32 * WP; i += NW * 64) g_s[(i / WP) * LDG + (i % WP)] = g[i];
     __syncthreads();
     PV_WT(0, 1);
-    // one tile: this wave's 32 units of g as the A operands of products (1) and (4) are the same for every visit and live in
-    // registers; several tiles: read from LDS where they are used
-    float g1[T == 1 ? 16 : 1], g4[T == 1 ? 16 : 1];
-    if constexpr (T == 1) {
+    // this wave's 32 units of g, as the A operands of products (1) and (4): the same for every visit
+    float g1[16], g4[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            g1[r] = g_s[c * LDG + w * 32 + PV_ROW(r, h)];    // A[i=b][k=unit]
-            g4[r] = g_s[PV_ROW(r, h) * LDG + w * 32 + c];    // A[i=unit_loc][k=b]
-        }
+    for (int r = 0; r < 16; ++r) {
+        g1[r] = g_s[c * LDG + w * 32 + PV_ROW(r, h)];    // A[i=b][k=unit]
+        g4[r] = g_s[PV_ROW(r, h) * LDG + w * 32 + c];    // A[i=unit_loc][k=b]
     }
 
-    f32x16 dg[T];
+    f32x16 dg;
 #pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dg[t][r] = 0.f;
+    for (int r = 0; r < 16; ++r) dg[r] = 0.f;
     float lossacc = 0.f;  // only the batch total enters the loss (popvae.py:423)
 
     for (int it = 0; blk < nblk; ++it) {
-        // several tiles: keep the (loop-invariant) g operand reads inside the loop, hoisted they would cost 32 T registers
-        if (T > 1) asm volatile("" ::: "memory");
         const int nb = block_of(it + 1) < nblk ? block_of(it + 1) : blk;  // past the end: a harmless re-read
         const int l = blk * 32 + c;
         const bool lvalid = l < L;
@@ -1169,106 +1153,73 @@ __global__ __launch_bounds__((PvDec2<NWB, T>::NW * 64), (PvDec2<NWB, T>::MINB)) 
         float cm = 0.f, cv = 0.f;
         {
             bias_n = cb[nb * 32 + c];
-#pragma unroll
-            for (int t = 0; t < T; ++t) xw_n[t] = Xt[((int64_t)t * nblk + nb) * 32 + c];
+            xw_n = Xt[nb * 32 + c];
             if (w == 0 && h == 0 && lvalid) {
                 cm = mC[l];
                 cv = vC[l];
             }
+            const f32x4* tM = reinterpret_cast<const f32x4*>(mV) + tb;
+            const f32x4* tVv = reinterpret_cast<const f32x4*>(vV) + tb;
             const f32x4* tVn = reinterpret_cast<const f32x4*>(V) + tile(nb);
 #pragma unroll
             for (int q = 0; q < 4; ++q) vn[q] = __builtin_nontemporal_load(tVn + q * 64);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                mq[q] = __builtin_nontemporal_load(tM + q * 64);
+                vq[q] = __builtin_nontemporal_load(tVv + q * 64);
+            }
         }
+        const uint64_t xs = xw >> (8 * h);
+        const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
+
+        // (1) logits a[b][l] over this wave's 32 units: M = b, N = l, K = unit.  A = g[b][unit], B = V fragment register.
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[r], vv[r >> 2][r & 3], a, 0, 0, 0);
+        }
+        if (NWB > 1) {
+            // the NWB waves of this SNP block meet; the other blocks of the workgroup run on
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 t4 = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+                reinterpret_cast<f32x4*>(vt)[q * 64 + lane] = t4;
+            }
+            ++nsync;
+            sync_ok &= pv_block_sync(&blk_sync[bsub][0], NWB * nsync, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 sum = reinterpret_cast<const f32x4*>(mb0)[q * 64 + lane];
+#pragma unroll
+                for (int w2 = 1; w2 < NWB; ++w2) sum += reinterpret_cast<const f32x4*>(mb0 + w2 * (2 * 32 * 33))[q * 64 + lane];
+                a[4 * q] = sum[0]; a[4 * q + 1] = sum[1]; a[4 * q + 2] = sum[2]; a[4 * q + 3] = sum[3];
+            }
+            // mailboxes double as the V^T staging tiles of product (3): nobody overwrites one before all have read it
+            sync_ok &= pv_block_sync(&blk_sync[bsub][1], NWB * nsync, lane);
+        }
+        // (2) sigmoid / BCE-from-logits / dlogits ; reg r <-> sample b = ROW(r,h), lane <-> SNP l (every wave of the block
+        //     computes the same values)
         float dbias = 0.f;
-        f32x16 dv;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dv[r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            if (t == T - 1) {  // the moments: requested a tile ahead of the Adam update (32 registers the other tiles need)
-                const f32x4* tM = reinterpret_cast<const f32x4*>(mV) + tb;
-                const f32x4* tVv = reinterpret_cast<const f32x4*>(vV) + tb;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    mq[q] = __builtin_nontemporal_load(tM + q * 64);
-                    vq[q] = __builtin_nontemporal_load(tVv + q * 64);
-                }
-            }
-            const float* gt = g_s + t * 32 * LDG + w * 32;  // tile t, this wave's 32 units
-            const uint64_t xs = xw[t] >> (8 * h);
-            const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
-            // (1) logits a[b][l] over this wave's 32 units: M = b, N = l, K = unit.  A = g[b][unit], B = V fragment register.
-            f32x16 a;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] = 0.f;
+auto sigmoid_bce = [&](auto Pc) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float ga = T == 1 ? g1[T == 1 ? r : 0] : gt[c * LDG + PV_ROW(r, h)];
-                a = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, vv[r >> 2][r & 3], a, 0, 0, 0);
+                const int b = PV_ROW(r, h);
+                const float x = 0.5f * pv_code(lo, hi, r);
+                const float z = a[r] + bias;
+                float bce, dz;
+                pv_bce<decltype(Pc)::value>(z, x, bce, dz);
+                const bool ok = lvalid && (b < nrows);
+                lossacc += (ok && w == 0) ? bce : 0.f;
+                const float d = ok ? dz * inv_b : 0.f;
+                a[r] = d;
+                dbias += d;
             }
-            if (NWB > 1) {
-                // the NWB waves of this SNP block meet; the other blocks of the workgroup run on
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 t4 = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
-                    reinterpret_cast<f32x4*>(vt)[q * 64 + lane] = t4;
-                }
-                ++nsync;
-                sync_ok &= pv_block_sync(&blk_sync[bsub][0], NWB * nsync, lane);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 sum = reinterpret_cast<const f32x4*>(mb0)[q * 64 + lane];
-#pragma unroll
-                    for (int w2 = 1; w2 < NWB; ++w2) sum += reinterpret_cast<const f32x4*>(mb0 + w2 * (2 * 32 * 33))[q * 64 + lane];
-                    a[4 * q] = sum[0]; a[4 * q + 1] = sum[1]; a[4 * q + 2] = sum[2]; a[4 * q + 3] = sum[3];
-                }
-                // mailboxes double as the V^T staging tiles of product (3): nobody overwrites one before all have read it
-                sync_ok &= pv_block_sync(&blk_sync[bsub][1], NWB * nsync, lane);
-            }
-            // (2) sigmoid / BCE / dlogits ; reg r <-> sample b = 32 t + ROW(r,h), lane <-> SNP l (every wave of the block
-            //     computes the same values)
-            auto sigmoid_bce = [&](auto Pc) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int b = 32 * t + PV_ROW(r, h);
-                    const float x = 0.5f * pv_code(lo, hi, r);
-                    const float z = a[r] + bias;
-                    float bce, dz;
-                    pv_bce<decltype(Pc)::value>(z, x, bce, dz);
-                    const bool ok = lvalid && (b < nrows);
-                    lossacc += (ok && w == 0) ? bce : 0.f;
-                    const float d = ok ? dz * inv_b : 0.f;
-                    a[r] = d;
-                    dbias += d;
-                }
-            };
-            if (bce_probs) sigmoid_bce(std::integral_constant<int, 1>{});
-            else sigmoid_bce(std::integral_constant<int, 0>{});
-            // (3) dg[b][unit] += sum_l da[b][l] * V[unit][l] : M = b, N = unit, K = l.  A needs da^T, B needs V^T (unit on
-            //     the lane): both staged through this wave's LDS tiles.
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dt[PV_ROW(r, h) * 33 + c] = a[r];                 // [b][l_loc]
-                vt[PV_ROW(r, h) * 33 + c] = vv[r >> 2][r & 3];    // [unit_loc][l_loc]
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float av = dt[c * 33 + PV_ROW(r, h)];  // A[i=b][k=l]
-                const float bv = vt[c * 33 + PV_ROW(r, h)];  // B[k=l][j=unit_loc]
-                dg[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, dg[t], 0, 0, 0);
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            // (4) dV[unit][l] += sum_b g[b][unit] * da[b][l] : M = unit, N = l, K = b (summed over the tiles)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float ga = T == 1 ? g4[T == 1 ? r : 0] : gt[PV_ROW(r, h) * LDG + c];  // A[i=unit_loc][k=b]
-                dv = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, a[r], dv, 0, 0, 0);
-            }
-        }
-        // bias: sum over the samples = registers + the other half-wave; block column 0 updates it
+        };
+        if (bce_probs) sigmoid_bce(std::integral_constant<int, 1>{});
+        else sigmoid_bce(std::integral_constant<int, 0>{});
+        // bias: sum over the 32 samples = 16 regs + the other half-wave; block column 0 updates it
         dbias += __shfl_xor(dbias, 32);
         if (w == 0 && h == 0 && lvalid) {
             float w_ = bias;
@@ -1277,7 +1228,31 @@ __global__ __launch_bounds__((PvDec2<NWB, T>::NW * 64), (PvDec2<NWB, T>::MINB)) 
             mC[l] = cm;
             vC[l] = cv;
         }
-        // Adam on the block
+        // (3) dg[b][unit] += sum_l da[b][l] * V[unit][l] : M = b, N = unit, K = l.  A needs da^T, B needs V^T (unit on the
+        //     lane): both staged through this wave's LDS tiles.
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dt[PV_ROW(r, h) * 33 + c] = a[r];                 // [b][l_loc]
+            vt[PV_ROW(r, h) * 33 + c] = vv[r >> 2][r & 3];    // [unit_loc][l_loc]
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float av = dt[c * 33 + PV_ROW(r, h)];  // A[i=b][k=l]
+            const float bv = vt[c * 33 + PV_ROW(r, h)];  // B[k=l][j=unit_loc]
+            dg = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, dg, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // (4) dV[unit][l] = sum_b g[b][unit] * da[b][l] : M = unit, N = l, K = b ; then Adam on the block
+        f32x16 dv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dv[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dv = __builtin_amdgcn_mfma_f32_32x32x2f32(g4[r], a[r], dv, 0, 0, 0);
+        }
         f32x4* oV = reinterpret_cast<f32x4*>(V2) + tb;
         f32x4* oM = reinterpret_cast<f32x4*>(mV2) + tb;
         f32x4* oVv = reinterpret_cast<f32x4*>(vV2) + tb;
@@ -1299,15 +1274,14 @@ __global__ __launch_bounds__((PvDec2<NWB, T>::NW * 64), (PvDec2<NWB, T>::MINB)) 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) vv[q] = vn[q];
-#pragma unroll
-        for (int t = 0; t < T; ++t) xw[t] = xw_n[t];
+        xw = xw_n;
         bias = bias_n;
         blk = block_of(it + 1);
     }
     // ---- per-workgroup reductions (fixed order) ----
     __syncthreads();  // everyone done with g_s / the staging tiles
     PV_WT(0, 2);
-    float* red = smem;  // [NW][T][16][64] for dg when BPI > 1, then [NW] loss
+    float* red = smem;  // [NW][16][64] for dg when BPI > 1, then [NW] loss
     lossacc += __shfl_xor(lossacc, 1);
     lossacc += __shfl_xor(lossacc, 2);
     lossacc += __shfl_xor(lossacc, 4);
@@ -1315,13 +1289,11 @@ __global__ __launch_bounds__((PvDec2<NWB, T>::NW * 64), (PvDec2<NWB, T>::MINB)) 
     lossacc += __shfl_xor(lossacc, 16);
     lossacc += __shfl_xor(lossacc, 32);
     if (!sync_ok) lossacc = __builtin_nanf("");  // a sync point gave up: make the step loudly wrong
-    float* lred = red + (BPI > 1 ? NW * T * 1024 : 0);
+    float* lred = red + NW * 1024;
     if (lane == 0) lred[wave] = lossacc;
     if (BPI > 1) {
 #pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[((wave * T + t) * 16 + r) * 64 + lane] = dg[t][r];
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = dg[r];
     }
     __syncthreads();
     if (tid == 0) {
@@ -1329,23 +1301,270 @@ __global__ __launch_bounds__((PvDec2<NWB, T>::NW * 64), (PvDec2<NWB, T>::MINB)) 
         for (int w2 = 0; w2 < NW; ++w2) sacc += lred[w2];
         losspart[blockIdx.x] = sacc;
     }
-    float* dgp = dgpart + (int64_t)blockIdx.x * (32 * T * WP);  // [32 T][WP]
+    float* dgp = dgpart + (int64_t)blockIdx.x * (32 * WP);
     if (BPI > 1) {
-        for (int e = tid; e < NWB * T * 1024; e += NW * 64) {
-            const int wq = e / (T * 1024), f = e % (T * 1024);  // block column, (tile, fragment element)
-            float sum = red[wq * (T * 1024) + f];
+        for (int e = tid; e < NWB * 1024; e += NW * 64) {
+            const int wq = e >> 10, f = e & 1023;  // block column, fragment element
+            float sum = red[wq * 1024 + f];
 #pragma unroll
-            for (int b2 = 1; b2 < BPI; ++b2) sum += red[(b2 * NWB + wq) * (T * 1024) + f];
-            const int t = f >> 10, r = (f >> 6) & 15, ln = f & 63;
-            dgp[(32 * t + PV_ROW(r, ln >> 5)) * WP + wq * 32 + (ln & 31)] = sum;
+            for (int b2 = 1; b2 < BPI; ++b2) sum += red[(b2 * NWB + wq) * 1024 + f];
+            const int r = f >> 6, ln = f & 63;
+            dgp[PV_ROW(r, ln >> 5) * WP + wq * 32 + (ln & 31)] = sum;
         }
     } else {
 #pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dgp[(32 * t + PV_ROW(r, h)) * WP + w * 32 + c] = dg[t][r];
+        for (int r = 0; r < 16; ++r) dgp[PV_ROW(r, h) * WP + w * 32 + c] = dg[r];
     }
     PV_WT(0, 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wide decoder, training pass for a batch of T = 2 or 4 row tiles (33 .. 128 rows) in ONE weight pass, width 128.
+// At T tiles a subtile visit is ~200 T matrix instructions and 16 T sigmoids against the same 96 KB of traffic: the kernel
+// is bound by the matrix pipe and the VALU, not by HBM, and what counts is that no lane does redundant arithmetic and no
+// wave waits for another more than it must.  So here the waves of a workgroup own ROW TILES, not block columns (pvk_dec2):
+// wave (sub, t) holds the whole subtile `sub` of V (64 registers) and does tile t's logits (full contraction, no exchange),
+// sigmoid / BCE, dg -- exactly pvk_dec's per-subtile work, once per tile and none of it twice.  Only dV = sum_t g_t^T da_t
+// has to meet: per block column w the T waves post their 32 x 32 fragment in LDS (double-buffered: one sync per column),
+// wave t == w % T sums them in tile order and does Adam on that column (so the update is spread over the waves too).
+// One workgroup (4 waves = 4 / T subtiles x T tiles) per CU, 512-register budget: V of the next visit is requested a
+// visit ahead, the moments of the columns a wave updates at the top of the visit.
+// LDS: g tiles [T][32][LDG] + per wave { dt [32][33], vt [32][33], post [2][16][64] } + bias-gradient slots.
+// ---------------------------------------------------------------------------------------------
+template <int T>
+struct PvDec3 {
+    static constexpr int NW = 4, SPW = NW / T;   // waves, subtiles per workgroup iteration
+    static constexpr int WP = 128, LDG = WP + 1;
+    static constexpr int WAVE_F = 2 * 32 * 33 + 2 * 1024;  // floats of LDS per wave
+    static constexpr size_t lds() {
+        const size_t work = (size_t)T * 32 * LDG + (size_t)NW * WAVE_F + NW * 32;
+        const size_t red = (size_t)NW * 4 * 1024 + NW;  // epilogue: dg fragments of all waves + loss
+        return (work > red ? work : red) * 4;
+    }
+};
+template <int T>
+__global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, const float* __restrict__ mV,
+                                                   const float* __restrict__ vV, float* __restrict__ V2, float* __restrict__ mV2,
+                                                   float* __restrict__ vV2, float* __restrict__ cb, float* __restrict__ mC,
+                                                   float* __restrict__ vC, const float* __restrict__ g,
+                                                   const uint64_t* __restrict__ Xt, int nblk, int L, const PvStep* st, PvAdam adam,
+                                                   float* __restrict__ dgpart, float* __restrict__ losspart, int ts) {
+    using G = PvDec3<T>;
+    constexpr int NW = G::NW, SPW = G::SPW, WP = G::WP, LDG = G::LDG, CPW = 4 / T;  // CPW: block columns a wave updates
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* g_s = smem;  // [T][32][LDG]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, h = lane >> 5;
+    float* wave_s = smem + T * 32 * LDG + wave * G::WAVE_F;
+    float* dt = wave_s;                 // [32][33]  da^T
+    float* vt = wave_s + 32 * 33;       // [32][33]  V^T of one block column
+    float* post = wave_s + 2 * 32 * 33; // [2][16][64] this wave's dV fragment of a block column (two in flight)
+    float* dbias_s = smem + T * 32 * LDG + NW * G::WAVE_F;  // [NW][32]
+    const int sub = wave / T, t = wave - sub * T;
+    const float* post0 = smem + T * 32 * LDG + (sub * T) * G::WAVE_F + 2 * 32 * 33;  // `post` of tile 0 of this subtile
+    const float* gt = g_s + t * 32 * LDG;
+    const int nrows = st->nrows;
+    const float inv_b = st->inv_b, alpha = st->alpha;
+    const int bce_probs = PV_BCE_MODE(st);
+    __shared__ int sub_sync[SPW];  // arrivals of the T waves of a subtile (only ever grows)
+    if (tid < SPW) sub_sync[tid] = 0;
+    bool sync_ok = true;
+    int nsync = 0;
+
+    auto subtile_of = [&](int it) { return (it * (int)gridDim.x + (int)blockIdx.x) * SPW + sub; };
+    f32x4 vv[4][4], vn[4][4];
+    uint64_t xw = 0, xw_n = 0;
+    float bias = 0.f, bias_n = 0.f;
+    int blk = subtile_of(0);
+    if (blk < nblk) {
+        const f32x4* tV = reinterpret_cast<const f32x4*>(V) + (int64_t)blk * ts + lane;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vv[w][q] = __builtin_nontemporal_load(tV + (w * 4 + q) * 64);
+        xw = Xt[((int64_t)t * nblk + blk) * 32 + c];
+        bias = cb[blk * 32 + c];
+    }
+    for (int i = tid; i < T * 32 * WP; i += NW * 64) g_s[(i / WP) * LDG + (i % WP)] = g[i];
+    __syncthreads();
+
+    f32x16 dg[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dg[w][r] = 0.f;
+    float lossacc = 0.f;
+    // (the wave's g operands are the same for every visit, but 128 more registers of them cost more in AGPR copies than
+    // the LDS reads they save: 832 vs 736 us at T = 2, 1M SNPs)
+
+    for (int it = 0; blk < nblk; ++it) {
+        const int nb = subtile_of(it + 1) < nblk ? subtile_of(it + 1) : blk;  // past the end: a harmless re-read
+        const int l = blk * 32 + c;
+        const bool lvalid = l < L;
+        const int64_t tb = (int64_t)blk * ts + lane;
+        // requests of this visit (the bias word first: it has landed before the next visit's sync points, behind which
+        // tile 0's wave rewrites the bias in place -- loads return in order)
+        bias_n = cb[nb * 32 + c];
+        xw_n = Xt[((int64_t)t * nblk + nb) * 32 + c];
+        float cm = 0.f, cv = 0.f;
+        if (t == 0 && h == 0 && lvalid) {
+            cm = mC[l];
+            cv = vC[l];
+        }
+        f32x4 mq[CPW][4], vq[CPW][4];
+#pragma unroll
+        for (int k = 0; k < CPW; ++k)  // this wave updates block columns t, t + T, ...
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                mq[k][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mV) + tb + ((t + k * T) * 4 + q) * 64);
+                vq[k][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vV) + tb + ((t + k * T) * 4 + q) * 64);
+            }
+        {
+            const f32x4* tVn = reinterpret_cast<const f32x4*>(V) + (int64_t)nb * ts + lane;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vn[w][q] = __builtin_nontemporal_load(tVn + (w * 4 + q) * 64);
+        }
+        const uint64_t xs = xw >> (8 * h);
+        const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
+        // (1) logits of tile t: M = b, N = l, K = unit (all 128)
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                a = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[c * LDG + w * 32 + PV_ROW(r, h)], vv[w][r >> 2][r & 3], a, 0, 0, 0);
+        // (2) sigmoid / BCE / dlogits of tile t
+        float dbias = 0.f;
+        auto sigmoid_bce = [&](auto Pc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = 32 * t + PV_ROW(r, h);
+                const float x = 0.5f * pv_code(lo, hi, r);
+                const float z = a[r] + bias;
+                float bce, dz;
+                pv_bce<decltype(Pc)::value>(z, x, bce, dz);
+                const bool ok = lvalid && (b < nrows);
+                lossacc += ok ? bce : 0.f;
+                const float d = ok ? dz * inv_b : 0.f;
+                a[r] = d;
+                dbias += d;
+            }
+        };
+        if (bce_probs) sigmoid_bce(std::integral_constant<int, 1>{});
+        else sigmoid_bce(std::integral_constant<int, 0>{});
+        dbias += __shfl_xor(dbias, 32);
+        if (h == 0) dbias_s[wave * 32 + c] = dbias;  // read by tile 0's wave behind the first sync below
+        // (3) dg[b][unit] += sum_l da[b][l] * V[unit][l], block column by block column (V^T through LDS)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dt[PV_ROW(r, h) * 33 + c] = a[r];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vt[PV_ROW(r, h) * 33 + c] = vv[w][r >> 2][r & 3];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dg[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(dt[c * 33 + PV_ROW(r, h)], vt[c * 33 + PV_ROW(r, h)], dg[w], 0, 0, 0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+        // (4) dV[unit][l] = sum over the tiles of g_t^T da_t, block column by block column: every wave posts its fragment,
+        //     wave w % T sums the T fragments in tile order and does Adam on the column
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            f32x16 dv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dv[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dv = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[PV_ROW(r, h) * LDG + w * 32 + c], a[r], dv, 0, 0, 0);
+            float* mine = post + (w & 1) * 1024;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 t4 = {dv[4 * q], dv[4 * q + 1], dv[4 * q + 2], dv[4 * q + 3]};
+                reinterpret_cast<f32x4*>(mine)[q * 64 + lane] = t4;
+            }
+            ++nsync;
+            sync_ok &= pv_block_sync(&sub_sync[sub], T * nsync, lane);
+            if (w % T == t) {
+                const int k = w / T;
+                const float* p0 = post0 + (w & 1) * 1024;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 gsum = reinterpret_cast<const f32x4*>(p0)[q * 64 + lane];
+#pragma unroll
+                    for (int t2 = 1; t2 < T; ++t2) gsum += reinterpret_cast<const f32x4*>(p0 + t2 * G::WAVE_F)[q * 64 + lane];
+                    f32x4 wq = vv[w][q], m4 = mq[k][q], v4 = vq[k][q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float w_ = wq[e], m_ = m4[e], v_ = v4[e];
+                        pv_adam(w_, m_, v_, gsum[e], alpha, adam);
+                        wq[e] = w_;
+                        m4[e] = m_;
+                        v4[e] = v_;
+                    }
+                    const int off = (w * 4 + q) * 64;
+                    __builtin_nontemporal_store(wq, reinterpret_cast<f32x4*>(V2) + tb + off);
+                    __builtin_nontemporal_store(m4, reinterpret_cast<f32x4*>(mV2) + tb + off);
+                    __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(vV2) + tb + off);
+                }
+            }
+            if (w == 0 && t == 0 && h == 0 && lvalid) {  // the output bias: sum of the tiles' parts, in tile order
+                float gb = dbias_s[(sub * T) * 32 + c];
+#pragma unroll
+                for (int t2 = 1; t2 < T; ++t2) gb += dbias_s[(sub * T + t2) * 32 + c];
+                float w_ = bias;
+                pv_adam(w_, cm, cv, gb, alpha, adam);
+                cb[l] = w_;
+                mC[l] = cm;
+                vC[l] = cv;
+            }
+        }
+        // the two `post` buffers alternate, and a wave overwrites buffer (w & 1) only two syncs after it was read: safe
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vv[w][q] = vn[w][q];
+        xw = xw_n;
+        bias = bias_n;
+        blk = subtile_of(it + 1);
+    }
+    // ---- per-workgroup reductions (fixed order) ----
+    __syncthreads();
+    float* red = smem;  // [NW][4][16][64], then [NW] loss
+    lossacc += __shfl_xor(lossacc, 1);
+    lossacc += __shfl_xor(lossacc, 2);
+    lossacc += __shfl_xor(lossacc, 4);
+    lossacc += __shfl_xor(lossacc, 8);
+    lossacc += __shfl_xor(lossacc, 16);
+    lossacc += __shfl_xor(lossacc, 32);
+    if (!sync_ok) lossacc = __builtin_nanf("");  // a sync point gave up: make the step loudly wrong
+    float* lred = red + NW * 4 * 1024;
+    if (lane == 0) lred[wave] = lossacc;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * 4 + w) * 16 + r) * 64 + lane] = dg[w][r];
+    __syncthreads();
+    if (tid == 0) {
+        float sacc = 0.f;
+        for (int w2 = 0; w2 < NW; ++w2) sacc += lred[w2];
+        losspart[blockIdx.x] = sacc;
+    }
+    // dgpart[workgroup][32 T][WP]: tile t2's rows = sum over the workgroup's subtiles of wave (sub2, t2)'s fragments
+    float* dgp = dgpart + (int64_t)blockIdx.x * (32 * T * WP);
+    for (int e = tid; e < T * 4 * 1024; e += NW * 64) {
+        const int t2 = e / 4096, f = e % 4096;  // tile, (block column, fragment element)
+        float sum = red[t2 * 4096 + f];
+#pragma unroll
+        for (int s2 = 1; s2 < SPW; ++s2) sum += red[(s2 * T + t2) * 4096 + f];
+        const int w = f >> 10, r = (f >> 6) & 15, ln = f & 63;
+        dgp[(32 * t2 + PV_ROW(r, ln >> 5)) * WP + w * 32 + (ln & 31)] = sum;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
