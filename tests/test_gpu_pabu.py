@@ -6,13 +6,14 @@ What can be pinned: the integer front end bit for bit (kept sites, imputed matri
 legacy stream), the file formats, and the README's qualitative criterion (README.md:99-103: the latent space separates the
 eastern and western populations, `k2pop` in the sample sheet).  The loss trajectory itself is **parity unpinned**: TF's
 shuffle and noise streams cannot be reproduced outside TF and the reference ships no output of this run."""
+import hashlib
 import json
 import os
 
 import numpy as np
 import pytest
 
-from popvae_amd import cli
+from popvae_amd import cli, prep
 
 pytestmark = pytest.mark.gpu
 
@@ -20,6 +21,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 VCF = os.path.join(HERE, "golden", "pabu_test_genotypes.vcf.gz")
 SHEET = os.path.join(HERE, "golden", "pabu_test_sample_data.txt")
 GOLD = json.load(open(os.path.join(HERE, "golden", "pabu_prep_seed42.json")))
+
+
+def test_integer_front_end_bit_exact_on_the_gpu_box():
+    """The integer path against the golden fixture on this machine too (same check as the CPU suite's: the native VCF reader,
+    biallelic / doubleton filter, binomial imputation on numpy's legacy stream, 2-bit packing, split)."""
+    gen, samples = prep.read_vcf(VCF)
+    assert hashlib.sha256(gen.tobytes()).hexdigest() == GOLD["gt_sha256"]
+    rng = prep.LegacyRNG(42)
+    packed, L, keep, af, nimp = prep.filter_impute_pack(gen, rng)
+    assert L == GOLD["n_snps"] and nimp == 22384
+    assert hashlib.sha256(packed.tobytes()).hexdigest() == GOLD["packed_sha256"]
+    tr, te = prep.train_test_split(gen.shape[1], 0.9, rng)
+    assert tr.tolist() == GOLD["train"] and te.tolist() == GOLD["test"]
 
 
 def test_reference_test_run_on_pabu(tmp_path, monkeypatch, capsys):

@@ -86,6 +86,8 @@ def test_loss_and_gradients(N, L, W, D, K, n):
     got = e.get_grads()
     for i, (a, b) in enumerate(zip(got, grads)):
         assert a.shape == b.shape
+        # element by element as well: relative 2e-4 on entries that carry signal, the tensor's float32 noise floor below
+        assert (np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-6 * np.abs(b).max()).all(), (i, np.abs(a - b).max())
         assert _relerr(a, b) <= RTOL, (i, _relerr(a, b))
     # eval step gives the same loss and leaves weights alone
     l2, _, _ = e.eval_step(rows, eps)
