@@ -111,6 +111,41 @@ def test_full_size_loss_and_gradients_vs_oracle(name, L, W, D, n):
     e.close()
 
 
+@pytest.mark.parametrize("name,L,D,B,n", [("C4-B128", 1_000_000, 6, 128, 128), ("C4-B64-short", 1_000_000, 6, 64, 50),
+                                          ("C2-B128-ragged", 100_000, 6, 128, 97)])
+def test_full_size_batches_in_one_weight_pass(name, L, D, B, n):
+    """--batch_size 33..128 at width 128 (popvae.py:26,497): 2 / 4 row tiles per weight pass (pvk_enc_fwd<4,T>, pvk_dec3<T>,
+    pvk_enc_bwd<4,TRAIN,0,T>).  One training step from zero moments at full SNP counts: loss vs the float64 oracle, and every
+    tensor's first moment = (1 - beta_1) * the oracle's gradient, to the same 1e-4."""
+    N, K, W = 150, 2, 128
+    codes = _codes(N, L, seed=L % 1000 + B)
+    w = O.init_weights(L, W, D, K, seed=7, dtype=np.float32)
+    g = np.random.default_rng(5)
+    for t in w:
+        if t.ndim == 1:
+            t += g.normal(0, 0.05, t.shape).astype(np.float32)
+    rows = g.choice(N, n, replace=False).astype(np.int32)
+    eps = g.normal(size=(n, K)).astype(np.float32)
+    e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=B, seed=0)
+    e.load_genotypes(_pack(codes))
+    e.set_weights(w)
+    loss, recon, kl = e.train_step(rows, eps)
+    w64 = [x.astype(np.float64) for x in w]
+    c = O.forward(w64, codes[rows] * 0.5, eps.astype(np.float64), D, K)
+    grads = O.backward(w64, c, D, K)
+    assert abs(loss - c["loss"]) <= RTOL * abs(c["loss"]), (loss, c["loss"])
+    assert abs(recon - c["recon"].mean()) <= RTOL * abs(c["recon"].mean())
+    del c, w64
+    for i, (a, b) in enumerate(zip(e.get_moments(0), grads)):
+        assert _relerr(a.astype(np.float64) * 10.0, b) <= RTOL, (name, "m", i, _relerr(a.astype(np.float64) * 10.0, b))
+    # a second step on other rows stays finite and is reproducible from the same state
+    rows2 = g.choice(N, n, replace=False).astype(np.int32)
+    l2, _, _ = e.eval_step(rows2, eps)
+    l3, _, _ = e.eval_step(rows2, eps)
+    assert np.isfinite(l2) and l2 == l3
+    e.close()
+
+
 @pytest.mark.parametrize("L,W,D", [(1_000_000, 128, 6), (500_000, 512, 6)])
 def test_epoch_loop_equals_stepwise_at_full_size(L, W, D):
     """pvae_train_epoch (next step's first-layer forward rides on the wide encoder backward) against a loop of

@@ -191,7 +191,10 @@ def test_large_batch_loss_and_gradients(N, L, W, D, K, B, n):
     e.close()
 
 
-@pytest.mark.parametrize("L,W,D,B", [(1000, 128, 3, 80), (700, 256, 2, 64)])
+# widths up to 128 on one rank: 2 row tiles (B <= 64) or 4 in one weight pass (pvk_enc_fwd<4,T> / pvk_dec3<T> / pvk_enc_bwd<..,T>);
+# width 256: 32-row tiles through the gradient dump
+@pytest.mark.parametrize("L,W,D,B", [(1000, 128, 3, 80), (700, 256, 2, 64), (1000, 128, 3, 64), (1100, 128, 4, 128),
+                                     (900, 96, 2, 100), (800, 32, 2, 48)])
 def test_large_batch_adam_steps_match_oracle(L, W, D, B):
     N, K = 150, 2
     dc, w = _problem(N, L, W, D, K, seed=13)
