@@ -37,6 +37,13 @@ __device__ unsigned long long pv_wtrace_buf[2 * 1024 * 6];  // points 0..3 = tim
 #else
 #define PV_WT(k, pt) do {} while (0)
 #endif
+// -DPV_DEC3_PROF (with -DPV_WTRACE): shader-clock cycles per phase of a pvk_dec3 visit, wave 0 of the first 256 workgroups
+#ifdef PV_DEC3_PROF
+#define PV_D3(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    d3acc[i] += t_ - d3last; d3last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PV_D3(i) do {} while (0)
+#endif
 #define PV_ROW(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))
 // index of element (row b, column n) of a 32 x 32 result in the [16][64] accumulator-ordered LDS tile: inverse of PV_ROW
 #define PV_TILE_IDX(b, n) (((((b) & 3) + 4 * ((b) >> 3)) << 6) + ((((b) >> 2) & 1) << 5) + (n))
@@ -102,19 +109,24 @@ __device__ __forceinline__ float pv_code(uint32_t lo, uint32_t hi, int r) {
 #else
 #define PV_BCE_MODE(st) ((st)->bce_probs)
 #endif
+// exp / log through the bare v_exp_f32 / v_log_f32 (base 2, 1 ulp): every argument below is a normal number (1 + e in [1, 2],
+// clipped probabilities in [1e-7, 1]), so the library forms' denormal scaling and two-constant ln 2 product (12 instructions
+// per log) buy nothing; the sigmoid / BCE phase of a subtile visit is VALU time on the critical path of the T-tile kernel.
 template <int PROBS>
 __device__ __forceinline__ void pv_bce(float z, float x, float& bce, float& d) {
-    const float e = __expf(-fabsf(z));                 // exp(-|z|)
-    const float inv = __builtin_amdgcn_rcpf(1.f + e);
+    const float kLn2 = 0.69314718056f, kLog2e = 1.44269504089f;
+    const float e = __builtin_amdgcn_exp2f(-kLog2e * fabsf(z));  // exp(-|z|)
+    const float s = 1.f + e;
+    const float inv = __builtin_amdgcn_rcpf(s);
     const float p = z >= 0.f ? inv : e * inv;          // sigmoid(z)
     if (!PROBS) {
-        bce = fmaxf(z, 0.f) - z * x + __logf(1.f + e);
+        bce = fmaf(__builtin_amdgcn_logf(s), kLn2, fmaf(-z, x, fmaxf(z, 0.f)));
         d = p - x;
     } else {
         const float e7 = 1e-7f;
         const float pc = fminf(fmaxf(p, e7), 1.f - e7);
         const float a1 = pc + e7, a0 = 1.f - pc + e7;
-        bce = -(x * __logf(a1) + (1.f - x) * __logf(a0));
+        bce = -kLn2 * (x * __builtin_amdgcn_logf(a1) + (1.f - x) * __builtin_amdgcn_logf(a0));
         const bool inside = p >= e7 && p <= 1.f - e7;
         d = inside ? ((1.f - x) * __builtin_amdgcn_rcpf(a0) - x * __builtin_amdgcn_rcpf(a1)) * (p * (1.f - p)) : 0.f;
     }
@@ -1324,20 +1336,42 @@ auto sigmoid_bce = [&](auto Pc) {
 // is bound by the matrix pipe and the VALU, not by HBM, and what counts is that no lane does redundant arithmetic and no
 // wave waits for another more than it must.  So here the waves of a workgroup own ROW TILES, not block columns (pvk_dec2):
 // wave (sub, t) holds the whole subtile `sub` of V (64 registers) and does tile t's logits (full contraction, no exchange),
-// sigmoid / BCE, dg -- exactly pvk_dec's per-subtile work, once per tile and none of it twice.  Only dV = sum_t g_t^T da_t
-// has to meet: per block column w the T waves post their 32 x 32 fragment in LDS (double-buffered: one sync per column),
-// wave t == w % T sums them in tile order and does Adam on that column (so the update is spread over the waves too).
+// sigmoid / BCE, dg -- exactly pvk_dec's per-subtile work, once per tile and none of it twice.  What the T waves of a
+// subtile share goes through LDS at two sync points per visit:
+//   C: V^T, which the dg product needs as its B operand, is staged once per subtile -- wave t transposes block columns
+//      t, t + T, ... and every wave reads all four (each wave staging all of V^T itself: 48 more LDS writes and 8 waits);
+//   A: dV = sum_t g_t^T da_t -- every wave posts its four 32 x 32 fragments, then wave t sums block columns t, t + T, ...
+//      over the tiles in tile order and does Adam on them, all waves at once (a sync per column serialised the updates:
+//      each sync waited for the one wave that was updating).
+// A third counter, B, is arrived at after the update and waited for only before the next visit's staging (the wave's da^T
+// tile aliases its post area), a whole logits + sigmoid phase later: it does not block in practice.
 // One workgroup (4 waves = 4 / T subtiles x T tiles) per CU, 512-register budget: V of the next visit is requested a
 // visit ahead, the moments of the columns a wave updates at the top of the visit.
-// LDS: g tiles [T][32][LDG] + per wave { dt [32][33], vt [32][33], post [2][16][64] } + bias-gradient slots.
+// LDS: g tiles [T][32][LDG] + per wave { post [4][16][64] (da^T [32][33] aliased), V^T columns [4/T][32][33] } + bias-gradient
+// slots (two sets, by visit parity).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pv_block_arrive(int* cnt, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's LDS accesses are done before it is counted
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ bool pv_block_wait(int* cnt, int target) {
+    bool ok = false;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok;
+}
+
 template <int T>
 struct PvDec3 {
-    static constexpr int NW = 4, SPW = NW / T;   // waves, subtiles per workgroup iteration
+    static constexpr int NW = 4, SPW = NW / T, CPW = 4 / T;   // waves, subtiles per workgroup iteration, block columns a wave updates
     static constexpr int WP = 128, LDG = WP + 1;
-    static constexpr int WAVE_F = 2 * 32 * 33 + 2 * 1024;  // floats of LDS per wave
+    static constexpr int WAVE_F = 4 * 1024 + CPW * 32 * 33;  // floats of LDS per wave
     static constexpr size_t lds() {
-        const size_t work = (size_t)T * 32 * LDG + (size_t)NW * WAVE_F + NW * 32;
+        const size_t work = (size_t)T * 32 * LDG + (size_t)NW * WAVE_F + 2 * NW * 32;
         const size_t red = (size_t)NW * 4 * 1024 + NW;  // epilogue: dg fragments of all waves + loss
         return (work > red ? work : red) * 4;
     }
@@ -1350,25 +1384,24 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
                                                    const uint64_t* __restrict__ Xt, int nblk, int L, const PvStep* st, PvAdam adam,
                                                    float* __restrict__ dgpart, float* __restrict__ losspart, int ts) {
     using G = PvDec3<T>;
-    constexpr int NW = G::NW, SPW = G::SPW, WP = G::WP, LDG = G::LDG, CPW = 4 / T;  // CPW: block columns a wave updates
+    constexpr int NW = G::NW, SPW = G::SPW, WP = G::WP, LDG = G::LDG, CPW = G::CPW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* g_s = smem;  // [T][32][LDG]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, h = lane >> 5;
-    float* wave_s = smem + T * 32 * LDG + wave * G::WAVE_F;
-    float* dt = wave_s;                 // [32][33]  da^T
-    float* vt = wave_s + 32 * 33;       // [32][33]  V^T of one block column
-    float* post = wave_s + 2 * 32 * 33; // [2][16][64] this wave's dV fragment of a block column (two in flight)
-    float* dbias_s = smem + T * 32 * LDG + NW * G::WAVE_F;  // [NW][32]
+    float* waves_s = smem + T * 32 * LDG;
+    float* post = waves_s + wave * G::WAVE_F;  // [4][16][64] this wave's dV fragments of the four block columns
+    float* dt = post;                          // [32][33]    da^T (dead before the first fragment is posted)
+    float* vtc = post + 4 * 1024;              // [CPW][32][33] V^T of block columns t, t + T, ...
+    float* dbias_s = waves_s + NW * G::WAVE_F;  // [2][NW][32]
     const int sub = wave / T, t = wave - sub * T;
-    const float* post0 = smem + T * 32 * LDG + (sub * T) * G::WAVE_F + 2 * 32 * 33;  // `post` of tile 0 of this subtile
+    const float* sub_s = waves_s + (sub * T) * G::WAVE_F;  // region of tile 0's wave of this subtile
     const float* gt = g_s + t * 32 * LDG;
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
     const int bce_probs = PV_BCE_MODE(st);
-    __shared__ int sub_sync[SPW];  // arrivals of the T waves of a subtile (only ever grows)
-    if (tid < SPW) sub_sync[tid] = 0;
+    __shared__ int sync_a[SPW], sync_b[SPW], sync_c[SPW];  // arrivals of the T waves of a subtile (only ever grow)
+    if (tid < SPW) sync_a[tid] = sync_b[tid] = sync_c[tid] = 0;
     bool sync_ok = true;
-    int nsync = 0;
 
     auto subtile_of = [&](int it) { return (it * (int)gridDim.x + (int)blockIdx.x) * SPW + sub; };
     f32x4 vv[4][4], vn[4][4];
@@ -1393,6 +1426,10 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) dg[w][r] = 0.f;
     float lossacc = 0.f;
+#ifdef PV_DEC3_PROF
+    unsigned long long d3acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d3last = __builtin_amdgcn_s_memtime();
+    int d3visits = 0;
+#endif
     // (the wave's g operands are the same for every visit, but 128 more registers of them cost more in AGPR copies than
     // the LDS reads they save: 832 vs 736 us at T = 2, 1M SNPs)
 
@@ -1405,26 +1442,14 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
         // tile 0's wave rewrites the bias in place -- loads return in order)
         bias_n = cb[nb * 32 + c];
         xw_n = Xt[((int64_t)t * nblk + nb) * 32 + c];
-        float cm = 0.f, cv = 0.f;
-        if (t == 0 && h == 0 && lvalid) {
-            cm = mC[l];
-            cv = vC[l];
-        }
+        // (every lane loads the bias moments, clamped: a branch here would end the scheduling region the requests are
+        // spread over.)  The 1 KB requests themselves are spread over the matrix phases: issued back to back by four waves
+        // in lock step they queued at the CU's address unit for ~4000 cycles per visit, every wave stalled at issue.
+        const int lc = l < L ? l : L - 1;
+        float cm = mC[lc], cv = vC[lc];
         f32x4 mq[CPW][4], vq[CPW][4];
-#pragma unroll
-        for (int k = 0; k < CPW; ++k)  // this wave updates block columns t, t + T, ...
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                mq[k][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mV) + tb + ((t + k * T) * 4 + q) * 64);
-                vq[k][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vV) + tb + ((t + k * T) * 4 + q) * 64);
-            }
-        {
-            const f32x4* tVn = reinterpret_cast<const f32x4*>(V) + (int64_t)nb * ts + lane;
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) vn[w][q] = __builtin_nontemporal_load(tVn + (w * 4 + q) * 64);
-        }
+        const f32x4* tVn = reinterpret_cast<const f32x4*>(V) + (int64_t)nb * ts + lane;
+        PV_D3(0);
         const uint64_t xs = xw >> (8 * h);
         const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
         // (1) logits of tile t: M = b, N = l, K = unit (all 128)
@@ -1434,11 +1459,23 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
 #pragma unroll
         for (int w = 0; w < 4; ++w)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+            for (int r = 0; r < 16; ++r) {
+                if ((r & 3) == 0) vn[w][r >> 2] = __builtin_nontemporal_load(tVn + (w * 4 + (r >> 2)) * 64);
                 a = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[c * LDG + w * 32 + PV_ROW(r, h)], vv[w][r >> 2][r & 3], a, 0, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {  // 4 operand reads, one request, 4 matrix instructions
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        PV_D3(1);
         // (2) sigmoid / BCE / dlogits of tile t
         float dbias = 0.f;
-        auto sigmoid_bce = [&](auto Pc) {
+        // full: every row of the tile and every SNP of the block exists (wave-uniform) -- straight-line code whose 16 values
+        // overlap each other's exp / rcp / log latencies; with the masks the compiler builds a branch per value
+        const bool full = (blk * 32 + 32 <= L) && (32 * t + 32 <= nrows);
+        auto sigmoid_bce = [&](auto Pc, auto Fc) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int b = 32 * t + PV_ROW(r, h);
@@ -1446,85 +1483,135 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
                 const float z = a[r] + bias;
                 float bce, dz;
                 pv_bce<decltype(Pc)::value>(z, x, bce, dz);
-                const bool ok = lvalid && (b < nrows);
-                lossacc += ok ? bce : 0.f;
-                const float d = ok ? dz * inv_b : 0.f;
-                a[r] = d;
-                dbias += d;
+                if (decltype(Fc)::value) {
+                    lossacc += bce;
+                    a[r] = dz * inv_b;
+                } else {
+                    const bool ok = lvalid && (b < nrows);
+                    lossacc += ok ? bce : 0.f;
+                    a[r] = ok ? dz * inv_b : 0.f;
+                }
+                dbias += a[r];
             }
         };
-        if (bce_probs) sigmoid_bce(std::integral_constant<int, 1>{});
-        else sigmoid_bce(std::integral_constant<int, 0>{});
+        using C0 = std::integral_constant<int, 0>;
+        using C1 = std::integral_constant<int, 1>;
+        if (full) {
+            if (bce_probs) sigmoid_bce(C1{}, C1{});
+            else sigmoid_bce(C0{}, C1{});
+        } else {
+            if (bce_probs) sigmoid_bce(C1{}, C0{});
+            else sigmoid_bce(C0{}, C0{});
+        }
         dbias += __shfl_xor(dbias, 32);
-        if (h == 0) dbias_s[wave * 32 + c] = dbias;  // read by tile 0's wave behind the first sync below
-        // (3) dg[b][unit] += sum_l da[b][l] * V[unit][l], block column by block column (V^T through LDS)
+        float* dbias_v = dbias_s + (it & 1) * NW * 32;  // read by tile 0's wave behind sync A; rewritten two visits on
+        if (h == 0) dbias_v[wave * 32 + c] = dbias;
+        PV_D3(2);
+        // (3) dg[b][unit] += sum_l da[b][l] * V[unit][l]: da^T and this wave's share of V^T go to LDS, then sync C
+        sync_ok &= pv_block_wait(&sync_b[sub], T * it);  // the other tiles' waves have read last visit's fragments
 #pragma unroll
         for (int r = 0; r < 16; ++r) dt[PV_ROW(r, h) * 33 + c] = a[r];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
+            if (w % T != t) continue;  // wave-uniform
 #pragma unroll
-            for (int r = 0; r < 16; ++r) vt[PV_ROW(r, h) * 33 + c] = vv[w][r >> 2][r & 3];
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dg[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(dt[c * 33 + PV_ROW(r, h)], vt[c * 33 + PV_ROW(r, h)], dg[w], 0, 0, 0);
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
+            for (int r = 0; r < 16; ++r) vtc[(w / T) * (32 * 33) + PV_ROW(r, h) * 33 + c] = vv[w][r >> 2][r & 3];
         }
-        // (4) dV[unit][l] = sum over the tiles of g_t^T da_t, block column by block column: every wave posts its fragment,
-        //     wave w % T sums the T fragments in tile order and does Adam on the column
+        PV_D3(3);
+        pv_block_arrive(&sync_c[sub], lane);
+        sync_ok &= pv_block_wait(&sync_c[sub], T * (it + 1));
+        PV_D3(4);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            f32x16 dv;
+            const float* vt = sub_s + (w % T) * G::WAVE_F + 4 * 1024 + (w / T) * (32 * 33);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dv[r] = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dv = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[PV_ROW(r, h) * LDG + w * 32 + c], a[r], dv, 0, 0, 0);
-            float* mine = post + (w & 1) * 1024;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 t4 = {dv[4 * q], dv[4 * q + 1], dv[4 * q + 2], dv[4 * q + 3]};
-                reinterpret_cast<f32x4*>(mine)[q * 64 + lane] = t4;
-            }
-            ++nsync;
-            sync_ok &= pv_block_sync(&sub_sync[sub], T * nsync, lane);
-            if (w % T == t) {
-                const int k = w / T;
-                const float* p0 = post0 + (w & 1) * 1024;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 gsum = reinterpret_cast<const f32x4*>(p0)[q * 64 + lane];
-#pragma unroll
-                    for (int t2 = 1; t2 < T; ++t2) gsum += reinterpret_cast<const f32x4*>(p0 + t2 * G::WAVE_F)[q * 64 + lane];
-                    f32x4 wq = vv[w][q], m4 = mq[k][q], v4 = vq[k][q];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float w_ = wq[e], m_ = m4[e], v_ = v4[e];
-                        pv_adam(w_, m_, v_, gsum[e], alpha, adam);
-                        wq[e] = w_;
-                        m4[e] = m_;
-                        v4[e] = v_;
-                    }
-                    const int off = (w * 4 + q) * 64;
-                    __builtin_nontemporal_store(wq, reinterpret_cast<f32x4*>(V2) + tb + off);
-                    __builtin_nontemporal_store(m4, reinterpret_cast<f32x4*>(mV2) + tb + off);
-                    __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(vV2) + tb + off);
+            for (int r = 0; r < 16; ++r) {
+                if (r % (16 / (2 * CPW)) == 0) {  // the moments of the columns this wave updates (t, t + T, ...): 8 CPW requests
+                    const int j = (w * 16 + r) / (16 / (2 * CPW));  // 0 .. 8 CPW - 1
+                    const int k = j / 8, q = (j >> 1) & 3;
+                    const int64_t o = tb + ((t + k * T) * 4 + q) * 64;
+                    if (j & 1) vq[k][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vV) + o);
+                    else mq[k][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mV) + o);
                 }
-            }
-            if (w == 0 && t == 0 && h == 0 && lvalid) {  // the output bias: sum of the tiles' parts, in tile order
-                float gb = dbias_s[(sub * T) * 32 + c];
-#pragma unroll
-                for (int t2 = 1; t2 < T; ++t2) gb += dbias_s[(sub * T + t2) * 32 + c];
-                float w_ = bias;
-                pv_adam(w_, cm, cv, gb, alpha, adam);
-                cb[l] = w_;
-                mC[l] = cm;
-                vC[l] = cv;
+                dg[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(dt[c * 33 + PV_ROW(r, h)], vt[c * 33 + PV_ROW(r, h)], dg[w], 0, 0, 0);
             }
         }
-        // the two `post` buffers alternate, and a wave overwrites buffer (w & 1) only two syncs after it was read: safe
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            if (i % (2 / CPW) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        PV_D3(5);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // the da^T reads are done before the fragments overwrite the tile
+        __builtin_amdgcn_wave_barrier();
+        // (4) dV[unit][l] = sum over the tiles of g_t^T da_t: every wave posts its four fragments, sync A, then wave t sums
+        //     block columns t, t + T, ... in tile order and does Adam on them
+        f32x16 dv[2];
+#pragma unroll
+        for (int w = 0; w <= 4; ++w) {
+            if (w < 4) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dv[w & 1][r] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dv[w & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[PV_ROW(r, h) * LDG + w * 32 + c], a[r], dv[w & 1], 0, 0, 0);
+            }
+            if (w > 0) {  // column w - 1's fragment, behind the matrix instructions of column w
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x16& pv = dv[(w - 1) & 1];
+                    const f32x4 t4 = {pv[4 * q], pv[4 * q + 1], pv[4 * q + 2], pv[4 * q + 3]};
+                    reinterpret_cast<f32x4*>(post + (w - 1) * 1024)[q * 64 + lane] = t4;
+                }
+            }
+        }
+        PV_D3(6);
+        pv_block_arrive(&sync_a[sub], lane);
+        sync_ok &= pv_block_wait(&sync_a[sub], T * (it + 1));
+        PV_D3(7);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w % T != t) continue;  // wave-uniform
+            const int k = w / T;
+            const float* p0 = sub_s + w * 1024;
+            f32x4 frag[4][T];  // all reads first: one LDS round trip per column instead of one per fragment
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int t2 = 0; t2 < T; ++t2) frag[q][t2] = reinterpret_cast<const f32x4*>(p0 + t2 * G::WAVE_F)[q * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 gsum = frag[q][0];
+#pragma unroll
+                for (int t2 = 1; t2 < T; ++t2) gsum += frag[q][t2];
+                f32x4 wq = vv[w][q], m4 = mq[k][q], v4 = vq[k][q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float w_ = wq[e], m_ = m4[e], v_ = v4[e];
+                    pv_adam(w_, m_, v_, gsum[e], alpha, adam);
+                    wq[e] = w_;
+                    m4[e] = m_;
+                    v4[e] = v_;
+                }
+                const int off = (w * 4 + q) * 64;
+                __builtin_nontemporal_store(wq, reinterpret_cast<f32x4*>(V2) + tb + off);
+                __builtin_nontemporal_store(m4, reinterpret_cast<f32x4*>(mV2) + tb + off);
+                __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(vV2) + tb + off);
+            }
+        }
+        if (t == 0 && h == 0 && lvalid) {  // the output bias: sum of the tiles' parts, in tile order
+            float gb = dbias_v[(sub * T) * 32 + c];
+#pragma unroll
+            for (int t2 = 1; t2 < T; ++t2) gb += dbias_v[(sub * T + t2) * 32 + c];
+            float w_ = bias;
+            pv_adam(w_, cm, cv, gb, alpha, adam);
+            cb[l] = w_;
+            mC[l] = cm;
+            vC[l] = cv;
+        }
+        PV_D3(8);
+        pv_block_arrive(&sync_b[sub], lane);
 #pragma unroll
         for (int w = 0; w < 4; ++w)
 #pragma unroll
@@ -1532,7 +1619,17 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
         xw = xw_n;
         bias = bias_n;
         blk = subtile_of(it + 1);
+        PV_D3(9);
+#ifdef PV_DEC3_PROF
+        ++d3visits;
+#endif
     }
+#ifdef PV_DEC3_PROF
+    if (tid == 0 && blockIdx.x < 256) {
+        for (int i = 0; i < 10; ++i) pv_wtrace_buf[blockIdx.x * 12 + i] = d3acc[i];
+        pv_wtrace_buf[blockIdx.x * 12 + 10] = d3visits;
+    }
+#endif
     // ---- per-workgroup reductions (fixed order) ----
     __syncthreads();
     float* red = smem;  // [NW][4][16][64], then [NW] loss
