@@ -132,6 +132,46 @@ __device__ __forceinline__ void pv_bce(float z, float x, float& bce, float& d) {
     }
 }
 
+// One 32 x 32 accumulator fragment of logits (lane = SNP column c, registers = rows PV_ROW(r, h) of the tile starting at batch row
+// row0) -> dlogits / B in place, BCE terms added to lossacc, the lane's column sum of dlogits to dbias.
+//   MASK: rows beyond nrows / SNPs beyond L (lvalid) may be missing.  Without it the 16 values are straight-line code that
+//         overlaps their exp / rcp / log latencies; with it the compiler builds a branch per value (~150 instructions each).
+//   LOSS: this wave's BCE terms count (several waves may hold the same logits; the others skip the logarithm).
+template <int PROBS, int MASK, int LOSS>
+__device__ __forceinline__ void pv_sigmoid_frag(f32x16& a, float bias, uint32_t lo, uint32_t hi, int h, int row0, int nrows,
+                                                bool lvalid, float inv_b, float& lossacc, float& dbias) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float x = 0.5f * pv_code(lo, hi, r);
+        const float z = a[r] + bias;
+        float bce, dz;
+        pv_bce<PROBS>(z, x, bce, dz);
+        if (MASK) {
+            const bool ok = lvalid && (row0 + PV_ROW(r, h) < nrows);
+            if (LOSS) lossacc += ok ? bce : 0.f;
+            a[r] = ok ? dz * inv_b : 0.f;
+        } else {
+            if (LOSS) lossacc += bce;
+            a[r] = dz * inv_b;
+        }
+        dbias += a[r];
+    }
+}
+// probs, full (no masks needed), loss: wave-uniform
+__device__ __forceinline__ void pv_sigmoid_bce(int probs, bool full, bool loss, f32x16& a, float bias, uint32_t lo, uint32_t hi,
+                                               int h, int row0, int nrows, bool lvalid, float inv_b, float& lossacc,
+                                               float& dbias) {
+#define PV_SB(P, M, Ls) pv_sigmoid_frag<P, M, Ls>(a, bias, lo, hi, h, row0, nrows, lvalid, inv_b, lossacc, dbias)
+    if (probs) {
+        if (full) { if (loss) PV_SB(1, 0, 1); else PV_SB(1, 0, 0); }
+        else      { if (loss) PV_SB(1, 1, 1); else PV_SB(1, 1, 0); }
+    } else {
+        if (full) { if (loss) PV_SB(0, 0, 1); else PV_SB(0, 0, 0); }
+        else      { if (loss) PV_SB(0, 1, 1); else PV_SB(0, 1, 0); }
+    }
+#undef PV_SB
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-step scalars
 // ---------------------------------------------------------------------------------------------
@@ -698,23 +738,8 @@ __global__ __launch_bounds__(256, 2) void pvk_dec(const float* __restrict__ V, c
             }
         // (2) sigmoid / BCE-from-logits / dlogits ; reg r <-> sample b = ROW(r,h), lane <-> SNP l
         float dbias = 0.f;
-        auto sigmoid_bce = [&](auto Pc) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int b = PV_ROW(r, h);
-                const float x = 0.5f * pv_code(lo, hi, r);
-                const float z = a[r] + bias;
-                float bce, dz;
-                pv_bce<decltype(Pc)::value>(z, x, bce, dz);
-                const bool ok = lvalid && (b < nrows);
-                lossacc += ok ? bce : 0.f;
-                const float d = ok ? dz * inv_b : 0.f;
-                a[r] = d;
-                dbias += d;
-            }
-        };
-        if (bce_probs) sigmoid_bce(std::integral_constant<int, 1>{});
-        else sigmoid_bce(std::integral_constant<int, 0>{});
+        pv_sigmoid_bce(bce_probs, (blk * 32 + 32 <= L) && nrows >= 32, true, a, bias, lo, hi, h, 0, nrows, lvalid, inv_b, lossacc,
+                       dbias);
         if (TRAIN) {
             // bias: sum over the 32 samples = 16 regs + the other half-wave
             dbias += __shfl_xor(dbias, 32);
@@ -944,6 +969,8 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void pvk_dec_grp(const float* __re
         const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
         // (2) sigmoid / BCE-from-logits / dlogits (every wave of the block computes the same values)
         float dbias = 0.f;
+        // (not pv_sigmoid_bce: its straight-line form holds more values in flight, and this kernel is at its register limit --
+        // 12 more spilled registers, +3 % at width 512)
         auto sigmoid_bce = [&](auto Pc) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1214,23 +1241,8 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
         // (2) sigmoid / BCE-from-logits / dlogits ; reg r <-> sample b = ROW(r,h), lane <-> SNP l (every wave of the block
         //     computes the same values)
         float dbias = 0.f;
-auto sigmoid_bce = [&](auto Pc) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int b = PV_ROW(r, h);
-                const float x = 0.5f * pv_code(lo, hi, r);
-                const float z = a[r] + bias;
-                float bce, dz;
-                pv_bce<decltype(Pc)::value>(z, x, bce, dz);
-                const bool ok = lvalid && (b < nrows);
-                lossacc += (ok && w == 0) ? bce : 0.f;
-                const float d = ok ? dz * inv_b : 0.f;
-                a[r] = d;
-                dbias += d;
-            }
-        };
-        if (bce_probs) sigmoid_bce(std::integral_constant<int, 1>{});
-        else sigmoid_bce(std::integral_constant<int, 0>{});
+        pv_sigmoid_bce(bce_probs, (blk * 32 + 32 <= L) && nrows >= 32, w == 0, a, bias, lo, hi, h, 0, nrows, lvalid, inv_b, lossacc,
+                       dbias);
         // bias: sum over the 32 samples = 16 regs + the other half-wave; block column 0 updates it
         dbias += __shfl_xor(dbias, 32);
         if (w == 0 && h == 0 && lvalid) {
@@ -1472,37 +1484,9 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
         PV_D3(1);
         // (2) sigmoid / BCE / dlogits of tile t
         float dbias = 0.f;
-        // full: every row of the tile and every SNP of the block exists (wave-uniform) -- straight-line code whose 16 values
-        // overlap each other's exp / rcp / log latencies; with the masks the compiler builds a branch per value
-        const bool full = (blk * 32 + 32 <= L) && (32 * t + 32 <= nrows);
-        auto sigmoid_bce = [&](auto Pc, auto Fc) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int b = 32 * t + PV_ROW(r, h);
-                const float x = 0.5f * pv_code(lo, hi, r);
-                const float z = a[r] + bias;
-                float bce, dz;
-                pv_bce<decltype(Pc)::value>(z, x, bce, dz);
-                if (decltype(Fc)::value) {
-                    lossacc += bce;
-                    a[r] = dz * inv_b;
-                } else {
-                    const bool ok = lvalid && (b < nrows);
-                    lossacc += ok ? bce : 0.f;
-                    a[r] = ok ? dz * inv_b : 0.f;
-                }
-                dbias += a[r];
-            }
-        };
-        using C0 = std::integral_constant<int, 0>;
-        using C1 = std::integral_constant<int, 1>;
-        if (full) {
-            if (bce_probs) sigmoid_bce(C1{}, C1{});
-            else sigmoid_bce(C0{}, C1{});
-        } else {
-            if (bce_probs) sigmoid_bce(C1{}, C0{});
-            else sigmoid_bce(C0{}, C0{});
-        }
+        // full: every row of the tile and every SNP of the block exists (wave-uniform)
+        pv_sigmoid_bce(bce_probs, (blk * 32 + 32 <= L) && (32 * t + 32 <= nrows), true, a, bias, lo, hi, h, 32 * t, nrows, lvalid,
+                       inv_b, lossacc, dbias);
         dbias += __shfl_xor(dbias, 32);
         float* dbias_v = dbias_s + (it & 1) * NW * 32;  // read by tile 0's wave behind sync A; rewritten two visits on
         if (h == 0) dbias_v[wave * 32 + c] = dbias;
