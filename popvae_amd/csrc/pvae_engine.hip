@@ -94,6 +94,7 @@ struct pvae_engine {
     float* xch1 = nullptr;              // exchange buffer 1: [32*Wp] dg_D + [32] recon
     float *dA = nullptr, *dB = nullptr, *dpre1 = nullptr, *dheads = nullptr, *dz = nullptr;
     uint64_t* Xt = nullptr;
+    uint64_t* Xr = nullptr;    // the gathered (untransposed) words of the batch: operand order of pvk_enc_fwd
     float* probs = nullptr;  // decoder.predict staging [32][L], allocated on first pvae_decode
     float* enc_out = nullptr;  // encoder.predict staging: per 32-row batch [32][Kh] heads + [32][Kz] z, read back once
     int64_t enc_out_cap = 0;   // in batches
@@ -107,6 +108,7 @@ struct pvae_engine {
     // pvk_enc_bwd <.., T>, pvk_dec3<T> and 2 T chain workers; activation buffers hold 32 T rows.  T == 1: off.
     int T = 1;
     int dec3_wgs = 0;          // grid of pvk_dec3<T> (one workgroup per CU, 4 / T subtiles per iteration)
+    int encf_mt_wgs = 0;       // grid of pvk_enc_fwd<4, T> (T > 1: no fused forward to match, two workgroups on every CU) = its partial tiles
     int encb_parts = 0;        // partial tiles [32][Wp] the fused forward of pvk_enc_bwd leaves in encpart (one per subtile slot)
     int64_t encpart_floats = 0;
     int64_t tile_floats = 0;
@@ -441,6 +443,13 @@ int run_dense_bwd(pvae_engine* e, Dense& d, const float* Y, const float* dY, flo
     return launch_check(e, "dense_bwd");
 }
 
+// pvk_enc_fwd is launched with this much (unused) dynamic LDS so that a CU takes two of its workgroups at most.  Its grid is
+// at most two workgroups per CU, but on its registers alone a CU would take four, and the dispatcher then packs some CUs with
+// three or four while others get none: the kernel is bound by the matrix pipe of the fullest SIMD (150 cycles per matrix
+// instruction per wave with two waves on a SIMD), and took 120 us at 1M SNPs with no loads at all against 98 us with no
+// matrix instructions (tools/trace_dec3.py, -DPV_EXP_NOLOAD / -DPV_EXP_NOMMA builds).
+static constexpr size_t kEncFwdLds = 60 * 1024;
+
 // stage A: batch gather/transposes + partial wide-encoder sums -> P (pre-bias, this rank's SNPs only)
 int stage_a(pvae_engine* e, int row_offset, bool need_xt, bool fwd_done = false, bool reduced = false) {
     int rc;
@@ -449,7 +458,7 @@ int stage_a(pvae_engine* e, int row_offset, bool need_xt, bool fwd_done = false,
         Timer t(e, C_GATHER);
         int pairs = (e->nblk + 1) / 2;
         hipLaunchKernelGGL(pvk_gather_transpose, dim3((pairs + 3) / 4), dim3(256), 0, e->stream, e->geno, e->row_bytes,
-                           e->d_rows, e->st, row_offset, e->nblk, e->Xt);
+                           e->d_rows, e->st, row_offset, e->nblk, e->Xt, fwd_done ? (uint64_t*)nullptr : e->Xr);
         if ((rc = launch_check(e, "gather_transpose"))) return rc;
     }
     if (fwd_done && reduced) {
@@ -461,8 +470,9 @@ int stage_a(pvae_engine* e, int row_offset, bool need_xt, bool fwd_done = false,
         if ((rc = launch_check(e, "enc_reduce"))) return rc;
     } else {
         Timer t(e, C_ENC_FWD);
-        PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_enc_fwd<N_>, dim3(e->enc_wgs), dim3(256), 0, e->stream, e->W1.w, e->geno,
-                                              e->row_bytes, e->d_rows, e->st, row_offset, e->nblk, e->ngrp, e->encpart, e->ts4));
+        PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_enc_fwd<N_>, dim3(e->enc_wgs), dim3(256), kEncFwdLds, e->stream, e->W1.w, e->geno,
+                                              e->row_bytes, e->d_rows, e->st, row_offset, e->nblk, e->ngrp, e->encpart, e->ts4,
+                                              need_xt ? (const uint64_t*)e->Xr : (const uint64_t*)nullptr));
         if ((rc = launch_check(e, "enc_fwd"))) return rc;
         hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(32 * e->Wp)), dim3(256), 0, e->stream, e->encpart, e->encb_parts, 32 * e->Wp,
                            0.5f, e->P, (const float*)nullptr, (float*)nullptr);
@@ -871,14 +881,14 @@ int multi_tile_launches(pvae_engine* e, int row_offset, float* d_out3) {
     {
         Timer t(e, C_GATHER);
         hipLaunchKernelGGL(pvk_gather_transpose, dim3(((e->nblk + 1) / 2 + 3) / 4, T), dim3(256), 0, e->stream, e->geno, e->row_bytes,
-                           e->d_rows, e->st, row_offset, e->nblk, e->Xt);
+                           e->d_rows, e->st, row_offset, e->nblk, e->Xt, e->Xr);
         if ((rc = launch_check(e, "gather_transpose"))) return rc;
     }
     {
         Timer t(e, C_ENC_FWD);
-        hipLaunchKernelGGL((pvk_enc_fwd<4, T>), dim3(e->enc_wgs), dim3(256), 0, e->stream, e->W1.w, e->geno, e->row_bytes, e->d_rows,
-                           e->st, row_offset, e->nblk, e->ngrp, e->encpart, e->ts4);
-        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(nR)), dim3(256), 0, e->stream, e->encpart, e->encb_parts, nR, 0.5f,
+        hipLaunchKernelGGL((pvk_enc_fwd<4, T>), dim3(e->encf_mt_wgs), dim3(256), kEncFwdLds, e->stream, e->W1.w, e->geno, e->row_bytes,
+                           e->d_rows, e->st, row_offset, e->nblk, e->ngrp, e->encpart, e->ts4, (const uint64_t*)e->Xr);
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(nR)), dim3(256), 0, e->stream, e->encpart, e->encf_mt_wgs, nR, 0.5f,
                            e->P, (const float*)nullptr, (float*)nullptr);
         if ((rc = launch_check(e, "enc_fwd"))) return rc;
     }
@@ -1182,6 +1192,8 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     CK(allocf(e, &e->dpre1, R * e->Wp));
     HK(hipMalloc(&e->Xt, e->T * e->Lp * sizeof(uint64_t)));
     HK(hipMemsetAsync(e->Xt, 0, e->T * e->Lp * sizeof(uint64_t), e->stream));
+    HK(hipMalloc(&e->Xr, e->T * e->Lp * sizeof(uint64_t)));
+    HK(hipMemsetAsync(e->Xr, 0, e->T * e->Lp * sizeof(uint64_t), e->stream));
 
     auto clampi = [](int64_t v, int64_t lo, int64_t hi) { return (int)std::min(hi, std::max(lo, v)); };
     CK(setup_kernel_attrs(e));
@@ -1227,6 +1239,8 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
             e->encb_parts = (int)(per_group * 4 / e->NWB);
             e->enc_wgs = e->encb_wgs;  // the stand-alone forward: same decomposition, bit-identical partial tiles
         }
+        // width 128: a workgroup's four waves are the block columns of one subtile slot
+        if (e->T > 1) e->encf_mt_wgs = (int)balance(e->nblk, (int64_t)cus * 2);
         if (e->ngrp == 1) e->dec_wgs = (int)((balance(e->nblk, (int64_t)cus * o_dec * 4) + 3) / 4);
         else {  // a workgroup takes dec_grp_waves / ngrp SNP blocks per iteration
             const int bpi = dec_grp_waves(e->ngrp) / e->ngrp;
@@ -1254,7 +1268,7 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
                     e->enc_wgs, e->dec_wgs, e->encb_wgs, e->dec_eval_wgs);
     }
     e->encpart_floats = (int64_t)e->encb_parts * 32 * e->Wp;  // what a one-tile pass needs (pvae_train_step_noalloc)
-    CK(allocf(e, &e->encpart, e->encpart_floats * e->T));
+    CK(allocf(e, &e->encpart, (int64_t)std::max(e->encb_parts, e->encf_mt_wgs) * 32 * e->Wp * e->T));
     if (e->T > 1) {
         hipDeviceProp_t prop2;
         HK(hipGetDeviceProperties(&prop2, e->dev));
@@ -1312,7 +1326,7 @@ int pvae_destroy(pvae_engine* e) {
     for (auto p : e->dpre_bufs) hipFree(p);
     hipFree(e->probs);
     hipFree(e->enc_out);
-    hipFree(e->Xt); hipFree(e->geno); hipFree(e->st); hipFree(e->d_rows); hipFree(e->d_ntotal); hipFree(e->d_counter);
+    hipFree(e->Xt); hipFree(e->Xr); hipFree(e->geno); hipFree(e->st); hipFree(e->d_rows); hipFree(e->d_ntotal); hipFree(e->d_counter);
     for (auto& ev : e->evs) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     for (auto& sl : e->slots) { if (sl.host) hipHostFree(sl.host); if (sl.ev) hipEventDestroy(sl.ev); }
     if (e->h_out3) hipHostFree(e->h_out3);

@@ -207,10 +207,12 @@ __global__ void pvk_tile_begin(PvStep* st, int nrows, float inv_b_total, int acc
 // ---------------------------------------------------------------------------------------------
 // Batch gather + 2-bit transpose: Xt[l] (u64, sample b at bits 2b) from the resident packed matrix.
 // One wave handles two SNP blocks (lanes 0-31 / 32-63 = sample b of block 2p / 2p+1).
+// Xr (optional): the gathered words themselves, Xr[blk * 32 + b] = row b's 32 codes of block blk -- the operand order of the
+// encoder forward, 256 contiguous bytes per block instead of 32 cache lines of the resident matrix (8 bytes used of each).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void pv_gather_block(const uint8_t* __restrict__ geno, int64_t row_bytes,
                                                 const int* __restrict__ rows, int nrows, int row_offset, int nblk,
-                                                uint64_t* __restrict__ Xt, int block) {
+                                                uint64_t* __restrict__ Xt, uint64_t* __restrict__ Xr, int block) {
     __shared__ uint64_t sm[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = lane & 31, half = lane >> 5;
@@ -222,6 +224,7 @@ __device__ __forceinline__ void pv_gather_block(const uint8_t* __restrict__ geno
         w = *reinterpret_cast<const uint64_t*>(geno + row * row_bytes + (int64_t)blk * 8);
     }
     sm[wave][lane] = w;
+    if (Xr && blk < nblk) Xr[(int64_t)blk * 32 + b] = w;
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0); wave-private LDS row, no barrier needed
     __builtin_amdgcn_wave_barrier();
     // lane (l = lane&31, half) assembles SNP l of block `blk`: bits 2l..2l+1 of each sample's word
@@ -237,11 +240,12 @@ __device__ __forceinline__ void pv_gather_block(const uint8_t* __restrict__ geno
 
 __global__ __launch_bounds__(256) void pvk_gather_transpose(const uint8_t* __restrict__ geno, int64_t row_bytes,
                                                             const int* __restrict__ rows, const PvStep* st,
-                                                            int row_offset, int nblk, uint64_t* __restrict__ Xt) {
+                                                            int row_offset, int nblk, uint64_t* __restrict__ Xt,
+                                                            uint64_t* __restrict__ Xr) {
     // blockIdx.y = 32-row tile of the device pass: its rows follow the previous tile's, its words the previous tile's array
     const int tile = blockIdx.y;
     pv_gather_block(geno, row_bytes, rows, max(0, min(32, st->nrows - 32 * tile)), row_offset + 32 * tile, nblk,
-                    Xt + (int64_t)tile * nblk * 32, blockIdx.x);
+                    Xt + (int64_t)tile * nblk * 32, Xr ? Xr + (int64_t)tile * nblk * 32 : nullptr, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -258,7 +262,8 @@ template <int NWB, int T = 1>
 __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1, const uint8_t* __restrict__ geno,
                                                    int64_t row_bytes, const int* __restrict__ rows,
                                                    const PvStep* st, int row_offset, int nblk, int ngrp,
-                                                   float* __restrict__ part, int ts) {
+                                                   float* __restrict__ part, int ts, const uint64_t* __restrict__ Xr) {
+    // Xr != NULL: the batch's words as pvk_gather_transpose left them (same values as the resident matrix's, compact)
     constexpr int WG_UNITS = NWB * 32;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int grp = blockIdx.x % ngrp, gw = (blockIdx.x / ngrp) * 4 + wave;
@@ -275,6 +280,10 @@ __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     auto mma = [&](const f32x4 (&wv)[4], const uint64_t (&xw)[T]) {
+#ifdef PV_EXP_NOMMA
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t][0] += (float)(uint32_t)xw[t] + wv[0][0] + wv[1][1] + wv[2][2] + wv[3][3];
+#else
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const uint64_t xs = xw[t] >> (8 * h);
@@ -283,20 +292,35 @@ __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1,
             for (int r = 0; r < 16; ++r)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv_code(lo, hi, r), wv[r >> 2][r & 3], acc[t], 0, 0, 0);
         }
+#endif
     };
     auto request = [&](f32x4 (&wv)[4], uint64_t (&xw)[T], int blk_) {
         const f32x4* tile = reinterpret_cast<const f32x4*>(W1) + ((int64_t)blk_ * ngrp + grp) * ts + w * 256 + lane;
+#ifdef PV_EXP_NOLOAD
+        if (blk_ >= 4 * nslots) return;  // later groups reuse what the first one loaded
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) wv[q] = __builtin_nontemporal_load(tile + q * 64);
 #pragma unroll
-        for (int t = 0; t < T; ++t) xw[t] = xrow[t] ? *reinterpret_cast<const uint64_t*>(xrow[t] + (int64_t)blk_ * 8) : 0ull;
+        for (int t = 0; t < T; ++t)
+            xw[t] = Xr ? Xr[((int64_t)t * nblk + blk_) * 32 + c]
+                       : xrow[t] ? *reinterpret_cast<const uint64_t*>(xrow[t] + (int64_t)blk_ * 8) : 0ull;
     };
     int blk = slot;
+#ifdef PV_DEC3_PROF
+    const unsigned long long ef_c0 = __builtin_amdgcn_s_memtime(), ef_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // four blocks (16 KiB per wave) requested before the first is used (a rotating four-buffer pipeline, each buffer
     // refilled as soon as it is used, measured slower: 132 vs 118 us at 1M SNPs)
+#ifdef PV_EXP_NOLOAD
+    f32x4 wv[4][4];
+    uint64_t xw[4][T];
+#endif
     for (; blk + 3 * nslots < nblk; blk += 4 * nslots) {
+#ifndef PV_EXP_NOLOAD
         f32x4 wv[4][4];
         uint64_t xw[4][T];
+#endif
 #pragma unroll
         for (int u = 0; u < 4; ++u) request(wv[u], xw[u], blk + u * nslots);
 #pragma unroll
@@ -308,6 +332,13 @@ __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1,
         request(wv, xw, blk);
         mma(wv, xw);
     }
+#ifdef PV_DEC3_PROF
+    if (T > 1 && threadIdx.x == 0 && blockIdx.x < 1024) {  // shader cycles and 100 MHz ticks of the sweep
+        asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[T - 1][15]));
+        pv_wtrace_buf[4096 + blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - ef_c0;
+        pv_wtrace_buf[4096 + blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - ef_r0;
+    }
+#endif
     const int ldp = ngrp * WG_UNITS;
     float* p = part + (int64_t)slot * (32 * T * ldp) + grp * WG_UNITS + w * 32 + c;
 #pragma unroll
@@ -1440,6 +1471,7 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
     float lossacc = 0.f;
 #ifdef PV_DEC3_PROF
     unsigned long long d3acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d3last = __builtin_amdgcn_s_memtime();
+    const unsigned long long d3rt0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz: in-kernel clock = cycles / this
     int d3visits = 0;
 #endif
     // (the wave's g operands are the same for every visit, but 128 more registers of them cost more in AGPR copies than
@@ -1612,6 +1644,7 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
     if (tid == 0 && blockIdx.x < 256) {
         for (int i = 0; i < 10; ++i) pv_wtrace_buf[blockIdx.x * 12 + i] = d3acc[i];
         pv_wtrace_buf[blockIdx.x * 12 + 10] = d3visits;
+        pv_wtrace_buf[blockIdx.x * 12 + 11] = __builtin_amdgcn_s_memrealtime() - d3rt0;
     }
 #endif
     // ---- per-workgroup reductions (fixed order) ----
@@ -2038,7 +2071,7 @@ __global__ __launch_bounds__(256) void pvk_step_begin_gather(PvStep* st, const i
     const int remaining = *n_total_ptr - step * batch;
     const int nrows = max(0, min(remaining, batch));
     if (blockIdx.x + 1 < gridDim.x) {
-        pv_gather_block(geno, row_bytes, rows, nrows, row_offset, nblk, Xt, (int)blockIdx.x - nred);
+        pv_gather_block(geno, row_bytes, rows, nrows, row_offset, nblk, Xt, nullptr, (int)blockIdx.x - nred);
         return;
     }
     const int i = threadIdx.x;
