@@ -45,11 +45,14 @@ def _two_pop(N, L, seed):
     return g.binomial(2, f) * 0.5, pop
 
 
-def test_fit_trajectory_matches_oracle():
-    N, L, W, D, K, B = 75, 1500, 64, 3, 2, 32
+@pytest.mark.parametrize("N,B,ntrain", [(75, 32, 67),       # the reference's default batch size
+                                         (150, 48, 131),     # --batch_size 48: two row tiles in one weight pass, ragged last batch
+                                         (300, 128, 270)])   # --batch_size 128: four row tiles; 270 = 128 + 128 + 14
+def test_fit_trajectory_matches_oracle(N, B, ntrain):
+    L, W, D, K = 1500, 64, 3, 2
     dc, _ = _two_pop(N, L, 0)
     w = O.init_weights(L, W, D, K, seed=4, dtype=np.float32)
-    train = np.random.default_rng(1).permutation(N)[:67]
+    train = np.random.default_rng(1).permutation(N)[:ntrain]
     test = np.setdiff1d(np.arange(N), train)
 
     def eps_fn(kind, epoch, step, shape):
