@@ -739,11 +739,11 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
         else PV_NARROW_BWD(PV_MODE_TRAIN);
 #undef PV_NARROW_BWD
         if (km == PV_MODE_GRAD)
-            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_GRAD>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam);
+            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_GRAD>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam, 1);
         else if (km == PV_MODE_TRAIN_ACC)
-            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN_ACC>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam);
+            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN_ACC>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam, 1);
         if (mode == 0 && !ride)
-            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam);
+            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam, 1);
         if ((rc = launch_check(e, "narrow_bwd"))) return rc;
         }
         if (mode == 1) return 0;
@@ -875,9 +875,13 @@ int fetch_out3(pvae_engine* e, float* out3) {
 // the noise set up by the caller): every kernel of the step sees T row tiles -- the wide kernels multiply the block they
 // hold with each tile's codes and sum dW / dV over the tiles before the one Adam update, the chain runs 2 T workers.
 template <int T>
-int multi_tile_launches(pvae_engine* e, int row_offset, float* d_out3) {
+int multi_tile_launches(pvae_engine* e, int row_offset, float* d_out3, int mode) {
+    // mode: 0 = the whole batch (Adam in the pass); chunks of a batch above 32 T rows: 2 = gradient dump (PvStep.acc: store / add),
+    // 4 = last chunk (Adam on this pass + the dump) -- the conventions of the 32-row tile path (run_tile)
     int rc;
     const int R = 32 * T, nR = R * e->Wp;
+    const int km = mode == 2 ? PV_MODE_GRAD : mode == 4 ? PV_MODE_TRAIN_ACC : PV_MODE_TRAIN;
+    if (mode != 0 && (!e->d_bwd_ops_grad || !e->Vout.g || !e->W1.g) && (rc = ensure_grad_bufs(e))) return rc;
     {
         Timer t(e, C_GATHER);
         hipLaunchKernelGGL(pvk_gather_transpose, dim3(((e->nblk + 1) / 2 + 3) / 4, T), dim3(256), 0, e->stream, e->geno, e->row_bytes,
@@ -899,37 +903,81 @@ int multi_tile_launches(pvae_engine* e, int row_offset, float* d_out3) {
     {
         Timer t(e, C_DEC);
         const int wgs = e->dec3_wgs;
-        hipLaunchKernelGGL(pvk_dec3<T>, dim3(wgs), dim3(256), PvDec3<T>::lds(), e->stream,
-                           (const float*)e->Vout.w, (const float*)e->Vout.m, (const float*)e->Vout.v, e->Vout.w2, e->Vout.m2, e->Vout.v2,
-                           e->cout.w, e->cout.m, e->cout.v, (const float*)e->g[e->D - 1], (const uint64_t*)e->Xt, e->nblk, (int)e->L,
-                           (const PvStep*)e->st, e->adam, e->dgpart, e->losspart, e->ts4);
-        e->Vout.swap();
+        float* nul = nullptr;
+        const bool upd = mode != 2;
+#define PV_DEC3_LAUNCH(MD)                                                                                                          \
+    hipLaunchKernelGGL((pvk_dec3<T, MD>), dim3(wgs), dim3(256), PvDec3<T>::lds(), e->stream, (const float*)e->Vout.w,                \
+                       (const float*)(upd ? e->Vout.m : nul), (const float*)(upd ? e->Vout.v : nul), upd ? e->Vout.w2 : nul,         \
+                       upd ? e->Vout.m2 : e->Vout.g, upd ? e->Vout.v2 : nul, e->cout.w, upd ? e->cout.m : e->cout.g,                 \
+                       upd ? e->cout.v : nul, (const float*)e->g[e->D - 1], (const uint64_t*)e->Xt, e->nblk, (int)e->L,              \
+                       (const PvStep*)e->st, e->adam, e->dgpart, e->losspart, e->ts4, (const float*)(mode == 4 ? e->Vout.g : nul),   \
+                       (const float*)(mode == 4 ? e->cout.g : nul))
+        if (km == PV_MODE_GRAD) PV_DEC3_LAUNCH(PV_MODE_GRAD);
+        else if (km == PV_MODE_TRAIN_ACC) PV_DEC3_LAUNCH(PV_MODE_TRAIN_ACC);
+        else PV_DEC3_LAUNCH(PV_MODE_TRAIN);
+#undef PV_DEC3_LAUNCH
+        if (upd) e->Vout.swap();
         hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(nR)), dim3(256), 0, e->stream, e->dgpart, wgs, nR, 1.0f,
                            e->xch1, e->losspart, e->xch1 + nR);
         if ((rc = launch_check(e, "dec"))) return rc;
     }
+    const PvBwdOp* table = km == PV_MODE_GRAD ? e->d_bwd_ops_grad : e->d_bwd_ops;
     {
         Timer t(e, C_NARROW_BWD);
         if ((rc = ensure_narrow_packed(e))) return rc;
-        hipLaunchKernelGGL(pvk_narrow_bwd<PV_MODE_TRAIN>, dim3(e->narrow_warm ? 8 * (e->n_bwd_ops + 1) : PVN_WORKERS * T),
-                           dim3(PVN_THREADS), pvn_lds_bwd(), e->stream, (const PvBwdOp*)e->d_bwd_ops, e->n_bwd_ops, e->xch1, e->Wp, e->kl,
-                           e->eps, e->headout, e->Kh, e->K, e->st, e->adam, d_out3, 1, (int)PVN_WORKERS * T);
+        const dim3 chain_grid(e->narrow_warm ? 8 * (e->n_bwd_ops + 1) : PVN_WORKERS * T);
+#define PV_NARROW_BWD_T(MD)                                                                                                        \
+    hipLaunchKernelGGL(pvk_narrow_bwd<MD>, chain_grid, dim3(PVN_THREADS), pvn_lds_bwd(), e->stream, table, e->n_bwd_ops, e->xch1,   \
+                       e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st, e->adam, d_out3, 1, (int)PVN_WORKERS * T)
+        if (km == PV_MODE_GRAD) {
+            PV_NARROW_BWD_T(PV_MODE_GRAD);
+            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_GRAD>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam, T);
+        } else if (km == PV_MODE_TRAIN_ACC) {
+            PV_NARROW_BWD_T(PV_MODE_TRAIN_ACC);
+            hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_TRAIN_ACC>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam, T);
+        } else {
+            PV_NARROW_BWD_T(PV_MODE_TRAIN);
+        }
+#undef PV_NARROW_BWD_T
         if ((rc = launch_check(e, "narrow_bwd"))) return rc;
     }
     {
         Timer t(e, C_ENC_BWD);
-        const int adam_units = 16 * e->n_bwd_ops, adam_wgs = (adam_units + 3) / 4;
-        hipLaunchKernelGGL((pvk_enc_bwd<4, PV_MODE_TRAIN, 0, T>), dim3(e->encb_wgs + adam_wgs), dim3(256), T * lds_enc_bwd(e->Wp),
-                           e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2, e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp,
-                           e->st, e->adam, (const uint8_t*)nullptr, (int64_t)0, (const int*)nullptr, 0, 0, (float*)nullptr, e->ts4,
-                           (const float*)nullptr, (const PvBwdOp*)e->d_bwd_ops, adam_units);
-        e->W1.swap();
+        const uint8_t* nog = nullptr;
+        const int* nor = nullptr;
+        float* nof = nullptr;
+        const PvBwdOp* noops = nullptr;
+        if (km == PV_MODE_GRAD) {
+            hipLaunchKernelGGL((pvk_enc_bwd<4, PV_MODE_GRAD, 0, T>), dim3(e->encb_wgs), dim3(256), T * lds_enc_bwd(e->Wp), e->stream,
+                               e->W1.w, (float*)nullptr, (float*)nullptr, (float*)nullptr, e->W1.g, (float*)nullptr, e->dpre1, e->Wp, e->Xt,
+                               e->nblk, e->ngrp, e->st, e->adam, nog, (int64_t)0, nor, 0, 0, nof, e->ts4, (const float*)nullptr, noops, 0);
+        } else if (km == PV_MODE_TRAIN_ACC) {
+            hipLaunchKernelGGL((pvk_enc_bwd<4, PV_MODE_TRAIN_ACC, 0, T>), dim3(e->encb_wgs), dim3(256), T * lds_enc_bwd(e->Wp), e->stream,
+                               e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2, e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st,
+                               e->adam, nog, (int64_t)0, nor, 0, 0, nof, e->ts4, (const float*)e->W1.g, noops, 0);
+            e->W1.swap();
+        } else {
+            const int adam_units = 16 * e->n_bwd_ops, adam_wgs = (adam_units + 3) / 4;
+            hipLaunchKernelGGL((pvk_enc_bwd<4, PV_MODE_TRAIN, 0, T>), dim3(e->encb_wgs + adam_wgs), dim3(256), T * lds_enc_bwd(e->Wp),
+                               e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2, e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp,
+                               e->st, e->adam, nog, (int64_t)0, nor, 0, 0, nof, e->ts4, (const float*)nullptr,
+                               (const PvBwdOp*)e->d_bwd_ops, adam_units);
+            e->W1.swap();
+        }
         if ((rc = launch_check(e, "enc_bwd"))) return rc;
     }
     return 0;
 }
-int multi_tile_train(pvae_engine* e, int row_offset, float* d_out3) {
-    return e->T == 2 ? multi_tile_launches<2>(e, row_offset, d_out3) : multi_tile_launches<4>(e, row_offset, d_out3);
+int multi_tile_train(pvae_engine* e, int row_offset, float* d_out3, int mode = 0) {
+    return e->T == 2 ? multi_tile_launches<2>(e, row_offset, d_out3, mode) : multi_tile_launches<4>(e, row_offset, d_out3, mode);
+}
+// chunk c of a batch of n_batch rows above 32 T (rows on the device at d_rows[row_offset ..], noise in place): nrows rows,
+// gradients dumped / accumulated, Adam in the last chunk -- one pass over the wide weights per 32 T rows
+int run_chunk(pvae_engine* e, int row_offset, int nrows, int n_batch, int c, bool last, float* d_out3) {
+    int rc;
+    hipLaunchKernelGGL(pvk_tile_begin, dim3(1), dim3(64), 0, e->stream, e->st, nrows, 1.f / (float)n_batch, c > 0 ? 1 : 0);
+    if ((rc = launch_check(e, "tile_begin"))) return rc;
+    return multi_tile_train(e, row_offset, d_out3, last ? 4 : 2);
 }
 
 // one 32-row tile of a larger batch (rows already on the device at d_rows[row_offset..]): forward, loss part,
@@ -971,9 +1019,20 @@ int full_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, 
         if ((rc = multi_tile_train(e, 0, e->d_loss))) return rc;
         return fetch_out3(e, out3);
     }
-    const int nt = (n + 31) / 32;
-    if ((rc = ensure_loss(e, nt))) return rc;
-    for (int t = 0; t < nt; ++t) {
+    const int R = 32 * e->T;
+    const bool chunks = mode == 0 && e->T > 1;  // above 32 T rows: one weight pass per 32 T rows
+    const int nt = chunks ? (n + R - 1) / R : (n + 31) / 32;
+    if (chunks) {
+        if ((rc = ensure_loss(e, nt))) return rc;
+        for (int c = 0; c < nt; ++c) {
+            const int nb = std::min(R, n - R * c);
+            // begin_batch uploads this chunk's rows (+ eps) and, on the first chunk, advances Adam's t
+            if ((rc = begin_batch(e, rows + R * c, nb, eps ? eps + (size_t)R * c * e->K : nullptr, c == 0, R))) return rc;
+            if ((rc = run_chunk(e, 0, nb, n, c, c == nt - 1, e->d_loss + 3 * c))) return rc;
+        }
+    }
+    if (!chunks && (rc = ensure_loss(e, nt))) return rc;
+    for (int t = 0; t < nt && !chunks; ++t) {
         const int nb = std::min(32, n - 32 * t);
         // begin_batch uploads this tile's rows (+ eps) and, on the first tile of a train step, advances Adam's t
         if ((rc = begin_batch(e, rows + 32 * t, nb, eps ? eps + (size_t)32 * t * e->K : nullptr, mode == 0 && t == 0))) return rc;
@@ -1169,8 +1228,9 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     T.push_back({T_COUT, 0, e->L, 0});
 
     // activations / scratch
-    // batches of 33 .. 128 rows in one weight pass: width 128 (four block columns, the fused chain), one rank
-    if (cfg->batch_size > 32 && cfg->batch_size <= 128 && e->Wp == 128 && cfg->world == 1 && 2 * e->D + 2 <= PVN_MAXOPS &&
+    // batches of 33 .. 128 rows in one weight pass, larger ones in chunks of 128 rows (gradients dumped between the chunks):
+    // width 128 (four block columns, the fused chain), one rank
+    if (cfg->batch_size > 32 && e->Wp == 128 && cfg->world == 1 && 2 * e->D + 2 <= PVN_MAXOPS &&
         !getenv("PVAE_NO_FUSED_NARROW") && !getenv("PVAE_NO_DEC2") && !getenv("PVAE_NO_MULTITILE"))
         e->T = cfg->batch_size <= 64 ? 2 : 4;
     const int64_t R = 32 * (int64_t)e->T;  // rows the activation buffers hold
@@ -1512,10 +1572,15 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
             HIPCHK(hipMemsetAsync(slot, 0, (size_t)3 * tp * sizeof(float), e->stream));
             hipLaunchKernelGGL(pvk_step_begin, dim3(1), dim3(64), 0, e->stream, e->st, (const int*)nullptr, nb, B, 0, phase == 0 ? 1 : 0,
                                e->adam.b1, e->adam.b2);
-            if (phase == 0 && e->T > 1 && nb > 32) {  // the whole batch in one weight pass
-                hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, 32 * e->T * e->K, e->cfg.seed, e->d_counter);
-                if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
-                if ((rc = multi_tile_train(e, base + s * B, slot))) return rc;
+            if (phase == 0 && e->T > 1 && nb > 32) {  // the whole batch in one weight pass, or one pass per 32 T rows
+                const int R = 32 * e->T, nc = (nb + R - 1) / R;
+                for (int c = 0; c < nc; ++c) {
+                    hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, R * e->K, e->cfg.seed, e->d_counter);
+                    if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
+                    if (nc == 1) rc = multi_tile_train(e, base + s * B, slot);
+                    else rc = run_chunk(e, base + s * B + R * c, std::min(R, nb - R * c), nb, c, c == nc - 1, slot + 3 * c);
+                    if (rc) return rc;
+                }
                 continue;
             }
             for (int t = 0; t * 32 < nb; ++t) {

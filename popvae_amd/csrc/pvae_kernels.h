@@ -1419,13 +1419,17 @@ struct PvDec3 {
         return (work > red ? work : red) * 4;
     }
 };
-template <int T>
+template <int T, int MODE = PV_MODE_TRAIN>
 __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, const float* __restrict__ mV,
                                                    const float* __restrict__ vV, float* __restrict__ V2, float* __restrict__ mV2,
                                                    float* __restrict__ vV2, float* __restrict__ cb, float* __restrict__ mC,
                                                    float* __restrict__ vC, const float* __restrict__ g,
                                                    const uint64_t* __restrict__ Xt, int nblk, int L, const PvStep* st, PvAdam adam,
-                                                   float* __restrict__ dgpart, float* __restrict__ losspart, int ts) {
+                                                   float* __restrict__ dgpart, float* __restrict__ losspart, int ts,
+                                                   const float* __restrict__ gV, const float* __restrict__ gC) {
+    // MODE (chunks of a batch above 32 T rows, same conventions as pvk_dec): PV_MODE_GRAD dumps dV / dc into mV2 / mC (plain
+    // tiles; PvStep.acc: store or add) and leaves V, c alone; PV_MODE_TRAIN_ACC adds the dump gV / gC to this pass's gradient
+    // before Adam.  The dump traffic is requested where it is used (these passes are bound by the matrix pipe).
     using G = PvDec3<T>;
     constexpr int NW = G::NW, SPW = G::SPW, WP = G::WP, LDG = G::LDG, CPW = G::CPW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1442,6 +1446,7 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
     const int nrows = st->nrows;
     const float inv_b = st->inv_b, alpha = st->alpha;
     const int bce_probs = PV_BCE_MODE(st);
+    const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
     __shared__ int sync_a[SPW], sync_b[SPW], sync_c[SPW];  // arrivals of the T waves of a subtile (only ever grow)
     if (tid < SPW) sync_a[tid] = sync_b[tid] = sync_c[tid] = 0;
     bool sync_ok = true;
@@ -1490,7 +1495,11 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
         // spread over.)  The 1 KB requests themselves are spread over the matrix phases: issued back to back by four waves
         // in lock step they queued at the CU's address unit for ~4000 cycles per visit, every wave stalled at issue.
         const int lc = l < L ? l : L - 1;
-        float cm = mC[lc], cv = vC[lc];
+        float cm = 0.f, cv = 0.f;
+        if (MODE != PV_MODE_GRAD) {
+            cm = mC[lc];
+            cv = vC[lc];
+        }
         f32x4 mq[CPW][4], vq[CPW][4];
         const f32x4* tVn = reinterpret_cast<const f32x4*>(V) + (int64_t)nb * ts + lane;
         PV_D3(0);
@@ -1542,7 +1551,7 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
             const float* vt = sub_s + (w % T) * G::WAVE_F + 4 * 1024 + (w / T) * (32 * 33);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (r % (16 / (2 * CPW)) == 0) {  // the moments of the columns this wave updates (t, t + T, ...): 8 CPW requests
+                if (MODE != PV_MODE_GRAD && r % (16 / (2 * CPW)) == 0) {  // the moments of the columns this wave updates (t, t + T, ...): 8 CPW requests
                     const int j = (w * 16 + r) / (16 / (2 * CPW));  // 0 .. 8 CPW - 1
                     const int k = j / 8, q = (j >> 1) & 3;
                     const int64_t o = tb + ((t + k * T) * 4 + q) * 64;
@@ -1601,6 +1610,15 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
                 f32x4 gsum = frag[q][0];
 #pragma unroll
                 for (int t2 = 1; t2 < T; ++t2) gsum += frag[q][t2];
+                const int off = (w * 4 + q) * 64;
+                const int64_t goff = (int64_t)blk * (4 * 256) + off + lane;  // gradient dumps are plain tiles
+                if (MODE == PV_MODE_GRAD) {
+                    f32x4* dump = reinterpret_cast<f32x4*>(mV2) + goff;
+                    if (acc_grads) gsum += __builtin_nontemporal_load(dump);
+                    __builtin_nontemporal_store(gsum, dump);
+                    continue;
+                }
+                if (MODE == PV_MODE_TRAIN_ACC) gsum += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gV) + goff);
                 f32x4 wq = vv[w][q], m4 = mq[k][q], v4 = vq[k][q];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1610,7 +1628,6 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
                     m4[e] = m_;
                     v4[e] = v_;
                 }
-                const int off = (w * 4 + q) * 64;
                 __builtin_nontemporal_store(wq, reinterpret_cast<f32x4*>(V2) + tb + off);
                 __builtin_nontemporal_store(m4, reinterpret_cast<f32x4*>(mV2) + tb + off);
                 __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(vV2) + tb + off);
@@ -1620,11 +1637,16 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
             float gb = dbias_v[(sub * T) * 32 + c];
 #pragma unroll
             for (int t2 = 1; t2 < T; ++t2) gb += dbias_v[(sub * T + t2) * 32 + c];
-            float w_ = bias;
-            pv_adam(w_, cm, cv, gb, alpha, adam);
-            cb[l] = w_;
-            mC[l] = cm;
-            vC[l] = cv;
+            if (MODE == PV_MODE_GRAD) {
+                mC[l] = acc_grads ? mC[l] + gb : gb;
+            } else {
+                if (MODE == PV_MODE_TRAIN_ACC) gb += gC[l];
+                float w_ = bias;
+                pv_adam(w_, cm, cv, gb, alpha, adam);
+                cb[l] = w_;
+                mC[l] = cm;
+                vC[l] = cv;
+            }
         }
         PV_D3(8);
         pv_block_arrive(&sync_b[sub], lane);
@@ -1925,40 +1947,46 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
     }
     // Gradient dump (MODE_GRAD) and Adam on this pass + the dump (MODE_TRAIN_ACC): tiles of a batch above 32 rows.  One
     // wave per subtile, round-robin; a workgroup stays on one unit group (gridDim.x is a multiple of ngrp).
-    static_assert(MODE == PV_MODE_TRAIN || (FUSE == 0 && T == 1), "fused forward / several row tiles: plain training pass only");
+    // T row tiles (chunks of a batch above 32 T rows): dpre is [32 T][ldp], Xt T word arrays, dW sums over the tiles.
+    static_assert(MODE == PV_MODE_TRAIN || FUSE == 0, "fused forward: plain training pass only");
     const int grp = blockIdx.x % ngrp;
     const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / ngrp) * 4 + wave), nslots = (gridDim.x / ngrp) * 4;
     const float alpha = st->alpha;
     const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
-    for (int i = tid; i < 32 * ldp; i += 256) {
+    for (int i = tid; i < 32 * T * ldp; i += 256) {
         const int b = i / ldp, u = i % ldp;
-        smem[((u / WG_UNITS) * 32 + b) * WG_UNITS + (u % WG_UNITS)] = dpre[i];
+        smem[((u / WG_UNITS) * (32 * T) + b) * WG_UNITS + (u % WG_UNITS)] = dpre[i];
     }
     __syncthreads();
     for (int blk = slot; blk < nblk; blk += nslots) {
         const int64_t t = (int64_t)blk * ngrp + grp;
-        const float* dp = smem + grp * 32 * WG_UNITS;
-        uint64_t xw = Xt[blk * 32 + c] >> (8 * h);
-        const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
-        float xa[16];
+        const float* dp = smem + grp * (32 * T) * WG_UNITS;
+        uint32_t lo[T], hi[T];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xa[r] = pv_code(lo, hi, r);
+        for (int tt = 0; tt < T; ++tt) {
+            const uint64_t xw = Xt[((int64_t)tt * nblk + blk) * 32 + c] >> (8 * h);
+            lo[tt] = (uint32_t)xw, hi[tt] = (uint32_t)(xw >> 32);
+        }
         const f32x4* tW = reinterpret_cast<const f32x4*>(W1) + t * ts;  // interleaved W|m|v tiles, see pvk_dec
         const f32x4* tM = reinterpret_cast<const f32x4*>(mW) + t * ts;
         const f32x4* tV = reinterpret_cast<const f32x4*>(vW) + t * ts;
         f32x4* oW = reinterpret_cast<f32x4*>(W1o) + t * ts;
         f32x4* oM = reinterpret_cast<f32x4*>(mWo) + t * (MODE == PV_MODE_GRAD ? (int64_t)(NWB * 256) : (int64_t)ts);
         f32x4* oV = reinterpret_cast<f32x4*>(vWo) + t * ts;
-#pragma unroll
+        // (T > 2: the block columns one at a time -- unrolled, the compiler keeps all 16 T codes and the LDS operands of four
+        // columns live and spills 100-260 registers)
+#pragma unroll(T > 2 ? 1 : NWB)
         for (int w = 0; w < NWB; ++w) {
             f32x16 dw;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dw[r] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float bv = dp[PV_ROW(r, h) * WG_UNITS + w * 32 + c];  // B[k=b][j=unit]
-                dw = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[r], bv, dw, 0, 0, 0);
-            }
+            for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float bv = dp[(32 * tt + PV_ROW(r, h)) * WG_UNITS + w * 32 + c];  // B[k=b][j=unit]
+                    dw = __builtin_amdgcn_mfma_f32_32x32x2f32(pv_code(lo[tt], hi[tt], r), bv, dw, 0, 0, 0);
+                }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int off = (w * 4 + q) * 64 + lane;

@@ -626,8 +626,8 @@ __device__ __forceinline__ void pvn_adam_unit(const PvBwdOp* __restrict__ ops, i
 
 template <int MODE>
 __global__ __launch_bounds__(64) void pvk_narrow_adam(const PvBwdOp* __restrict__ ops, const PvStep* __restrict__ st,
-                                                      PvAdam adam) {
-    pvn_adam_unit<MODE>(ops, blockIdx.x, blockIdx.y, threadIdx.x, st, adam, 1);
+                                                      PvAdam adam, int ntiles) {
+    pvn_adam_unit<MODE>(ops, blockIdx.x, blockIdx.y, threadIdx.x, st, adam, ntiles);
 }
 
 // Per-layer path (widths above 128): the narrow layers' dW + Adam units and, as one more row of the grid, the wide first

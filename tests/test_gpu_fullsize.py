@@ -112,12 +112,14 @@ def test_full_size_loss_and_gradients_vs_oracle(name, L, W, D, n):
 
 
 @pytest.mark.parametrize("name,L,D,B,n", [("C4-B128", 1_000_000, 6, 128, 128), ("C4-B64-short", 1_000_000, 6, 64, 50),
-                                          ("C2-B128-ragged", 100_000, 6, 128, 97)])
+                                          ("C2-B128-ragged", 100_000, 6, 128, 97),
+                                          # above 128 rows: chunks of 128 with gradient dumps in between (200 = 128 + 72, 300 = 128 + 128 + 44)
+                                          ("C4-B256-chunks", 1_000_000, 6, 256, 200), ("C2-B512-chunks", 100_000, 6, 512, 300)])
 def test_full_size_batches_in_one_weight_pass(name, L, D, B, n):
     """--batch_size 33..128 at width 128 (popvae.py:26,497): 2 / 4 row tiles per weight pass (pvk_enc_fwd<4,T>, pvk_dec3<T>,
     pvk_enc_bwd<4,TRAIN,0,T>).  One training step from zero moments at full SNP counts: loss vs the float64 oracle, and every
     tensor's first moment = (1 - beta_1) * the oracle's gradient, to the same 1e-4."""
-    N, K, W = 150, 2, 128
+    N, K, W = max(150, n + 20), 2, 128
     codes = _codes(N, L, seed=L % 1000 + B)
     w = O.init_weights(L, W, D, K, seed=7, dtype=np.float32)
     g = np.random.default_rng(5)

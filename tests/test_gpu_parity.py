@@ -193,10 +193,11 @@ def test_large_batch_loss_and_gradients(N, L, W, D, K, B, n):
 
 # widths up to 128 on one rank: 2 row tiles (B <= 64) or 4 in one weight pass (pvk_enc_fwd<4,T> / pvk_dec3<T> / pvk_enc_bwd<..,T>);
 # width 256: 32-row tiles through the gradient dump
+# above 128 rows: chunks of 128 (gradient dumps between the chunks, Adam in the last one): 200 = 128 + 72, 300 = 128 + 128 + 44
 @pytest.mark.parametrize("L,W,D,B", [(1000, 128, 3, 80), (700, 256, 2, 64), (1000, 128, 3, 64), (1100, 128, 4, 128),
-                                     (900, 96, 2, 100), (800, 32, 2, 48)])
+                                     (900, 96, 2, 100), (800, 32, 2, 48), (1000, 128, 3, 200), (900, 64, 2, 300)])
 def test_large_batch_adam_steps_match_oracle(L, W, D, B):
-    N, K = 150, 2
+    N, K = max(150, B + 20), 2
     dc, w = _problem(N, L, W, D, K, seed=13)
     e = _mk(dc, w, W, D, K, B=B)
     wo = [x.astype(np.float32).astype(np.float64) for x in w]
@@ -245,14 +246,14 @@ def test_large_batch_epoch_learns():
     e.close()
 
 
-@pytest.mark.parametrize("B,n_train", [(72, 170), (64, 161), (64, 20), (96, 32), (80, 80)])
+@pytest.mark.parametrize("B,n_train", [(72, 170), (64, 161), (64, 20), (96, 32), (80, 80), (160, 400), (260, 300)])
 def test_large_batch_epoch_equals_stepwise(B, n_train):
     """pvae_train_epoch with batch_size > 32 against a loop of pvae_train_step / pvae_eval_step calls on the same rows and
     the same engine noise stream (one draw per 32-row tile on both paths): same per-batch losses, same weights and Adam
     moments.  Batch shapes: 72/72/26 and 64/64/33 (short last batch of one tile / of a full tile + one row), 20 and 32
     rows in all (n_train <= 32 < batch_size: the only batch is a single tile), 80 (no short batch).  The stepwise path is
     the one test_large_batch_adam_steps_match_oracle pins against the oracle."""
-    N, L, W, D, K = 200, 900, 128, 3, 2
+    N, L, W, D, K = max(200, n_train + 45), 900, 128, 3, 2  # 160: 128 + 32, short last batch 80; 260: 128 + 128 + 4, then 40
     dc, w = _problem(N, L, W, D, K, seed=31)
     g = np.random.default_rng(7)
     perm = g.permutation(N)[:n_train].astype(np.int32)

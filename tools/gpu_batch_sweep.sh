@@ -16,4 +16,8 @@ for SHAPE in C4 C2; do
     [ $B -gt 32 ] && run "   tiles: " PVAE_NO_MULTITILE=1
   done
 done
-SHAPE=C4 STEPS=10 B=512; run "" X=1
+for B in 256 512; do
+  SHAPE=C4 STEPS=10; run "" X=1
+  run "   tiles: " PVAE_NO_MULTITILE=1
+done
+SHAPE=C2 STEPS=10 B=512; run "" X=1
