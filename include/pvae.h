@@ -31,7 +31,7 @@ typedef struct pvae_config {
     int32_t width;         /* --width  (popvae.py:78-80) */
     int32_t depth;         /* --depth  (popvae.py:75-77) */
     int32_t latent_dim;    /* --latent_dim (popvae.py:104-106) */
-    int32_t batch_size;    /* --batch_size (popvae.py:26); above 32 rows at width <= 128 on one rank: one pass over the wide weights per 128 rows; otherwise 32-row tiles; gradients accumulated, one Adam update either way */
+    int32_t batch_size;    /* --batch_size (popvae.py:26); above 32 rows at width <= 128: one pass over the wide weights per 128 rows; otherwise 32-row tiles; gradients accumulated, one Adam update either way */
     float lr, beta1, beta2, eps; /* Keras Adam defaults 1e-3, .9, .999, 1e-7 (popvae.py:426) */
     int32_t device_id;
     int32_t rank, world;   /* SNP-axis shard id / count */

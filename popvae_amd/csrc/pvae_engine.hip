@@ -412,12 +412,13 @@ PvRccl* rccl() {
     return &r;
 }
 // SUM all-reduce of exchange buffer `which` over the shards, in place, on the engine's stream; nothing to do on one rank
-int shard_allreduce(pvae_engine* e, int which) {
+// rows: rows of the device pass whose partial sums are exchanged (32; 32 T in a multi-tile pass)
+int shard_allreduce(pvae_engine* e, int which, int rows = 32) {
     if (e->cfg.world == 1 && !e->comm) return 0;  // a one-rank communicator (rehearsal on one GPU) is still driven
     if (!e->comm) return set_err(e, -5, "world > 1 without a communicator: call pvae_comm_init, or drive the step through "
                                         "pvae_stage_a/b/c with all-reduces in between");
     float* buf = which == 0 ? e->P : e->xch1;
-    const size_t n = which == 0 ? (size_t)32 * e->Wp : (size_t)32 * e->Wp + 32;
+    const size_t n = which == 0 ? (size_t)rows * e->Wp : (size_t)rows * e->Wp + 32;  // dg rows, then the loss sums
     Timer t(e, which == 0 ? C_XCH0 : C_XCH1);
     const int rc = rccl()->AllReduce(buf, buf, n, 7 /* ncclFloat32 */, 0 /* ncclSum */, e->comm, e->stream);
     if (rc) return set_err(e, -12, "ncclAllReduce: %s", rccl()->GetErrorString(rc));
@@ -896,6 +897,7 @@ int multi_tile_launches(pvae_engine* e, int row_offset, float* d_out3, int mode)
                            e->P, (const float*)nullptr, (float*)nullptr);
         if ((rc = launch_check(e, "enc_fwd"))) return rc;
     }
+    if ((rc = shard_allreduce(e, 0, R))) return rc;
     {
         Timer t(e, C_NARROW_FWD);
         if ((rc = narrow_fused_fwd(e, false, false, T))) return rc;
@@ -921,6 +923,7 @@ int multi_tile_launches(pvae_engine* e, int row_offset, float* d_out3, int mode)
                            e->xch1, e->losspart, e->xch1 + nR);
         if ((rc = launch_check(e, "dec"))) return rc;
     }
+    if ((rc = shard_allreduce(e, 1, R))) return rc;
     const PvBwdOp* table = km == PV_MODE_GRAD ? e->d_bwd_ops_grad : e->d_bwd_ops;
     {
         Timer t(e, C_NARROW_BWD);
@@ -1229,8 +1232,9 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
 
     // activations / scratch
     // batches of 33 .. 128 rows in one weight pass, larger ones in chunks of 128 rows (gradients dumped between the chunks):
-    // width 128 (four block columns, the fused chain), one rank
-    if (cfg->batch_size > 32 && e->Wp == 128 && cfg->world == 1 && 2 * e->D + 2 <= PVN_MAXOPS &&
+    // width 128 (four block columns, the fused chain).  Under SNP sharding the two exchanges of such a pass carry 32 T rows
+    // (engine-owned communicator; the host-driven staged calls stay at 32 rows per call and ignore T)
+    if (cfg->batch_size > 32 && e->Wp == 128 && 2 * e->D + 2 <= PVN_MAXOPS &&
         !getenv("PVAE_NO_FUSED_NARROW") && !getenv("PVAE_NO_DEC2") && !getenv("PVAE_NO_MULTITILE"))
         e->T = cfg->batch_size <= 64 ? 2 : 4;
     const int64_t R = 32 * (int64_t)e->T;  // rows the activation buffers hold
