@@ -108,6 +108,7 @@ struct pvae_engine {
     // pvk_enc_bwd <.., T>, pvk_dec3<T> and 2 T chain workers; activation buffers hold 32 T rows.  T == 1: off.
     int T = 1;
     int dec3_wgs = 0;          // grid of pvk_dec3<T> (one workgroup per CU, 4 / T subtiles per iteration)
+    int dece_mt_wgs = 0;       // grid of pvk_dec_eval_mt<T> (two workgroups per CU: the T g tiles are 16.5 T KB of LDS)
     int encf_mt_wgs = 0;       // grid of pvk_enc_fwd<4, T> (T > 1: no fused forward to match, two workgroups on every CU) = its partial tiles
     int encb_parts = 0;        // partial tiles [32][Wp] the fused forward of pvk_enc_bwd leaves in encpart (one per subtile slot)
     int64_t encpart_floats = 0;
@@ -295,6 +296,7 @@ void flush_timing(pvae_engine* e) {
 // ---- dynamic-LDS sizes ----
 size_t lds_dense_fwd(int K) { return (size_t)(32 * (K + 1) + 4096) * 4; }
 size_t lds_dense_bwd(int N) { return (size_t)(2 * 32 * (N + 1) + 4096) * 4; }
+static size_t lds_dec_eval_mt(int T) { return (size_t)T * 32 * 129 * sizeof(float); }  // the T g tiles
 // evaluation launches of pvk_dec use no per-wave staging tiles and no dg reduction: the g tile alone (more blocks per CU)
 size_t lds_dec_eval(int NWB) { return (size_t)(32 * (NWB * 32 + 1) + 64) * 4; }
 size_t lds_dec(int NWB) { return (size_t)(32 * (NWB * 32 + 1) + 4 * 3 * 32 * 33) * 4; }
@@ -328,13 +330,20 @@ int setup_kernel_attrs(pvae_engine* e) {
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN, 1>), lds_enc_bwd(e->Wp)));        \
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_GRAD, 0>), lds_enc_bwd(e->Wp)));         \
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN_ACC, 0>), lds_enc_bwd(e->Wp)));
+#define PV_ATTR_MT(TT)                                                                                     \
+    HIPCHK(allow_lds((pvk_dec3<TT, PV_MODE_TRAIN>), PvDec3<TT>::lds()));                                    \
+    HIPCHK(allow_lds((pvk_dec3<TT, PV_MODE_GRAD>), PvDec3<TT>::lds()));                                     \
+    HIPCHK(allow_lds((pvk_dec3<TT, PV_MODE_TRAIN_ACC>), PvDec3<TT>::lds()));                                \
+    HIPCHK(allow_lds((pvk_enc_bwd<4, PV_MODE_TRAIN, 0, TT>), TT * lds_enc_bwd(e->Wp)));                     \
+    HIPCHK(allow_lds((pvk_enc_bwd<4, PV_MODE_GRAD, 0, TT>), TT * lds_enc_bwd(e->Wp)));                      \
+    HIPCHK(allow_lds((pvk_enc_bwd<4, PV_MODE_TRAIN_ACC, 0, TT>), TT * lds_enc_bwd(e->Wp)));                 \
+    HIPCHK(allow_lds(pvk_dec_eval_mt<TT>, lds_dec_eval_mt(TT)));
     if (e->T == 2) {
-        HIPCHK(allow_lds(pvk_dec3<2>, PvDec3<2>::lds()));
-        HIPCHK(allow_lds((pvk_enc_bwd<4, PV_MODE_TRAIN, 0, 2>), 2 * lds_enc_bwd(e->Wp)));
+        PV_ATTR_MT(2)
     } else if (e->T == 4) {
-        HIPCHK(allow_lds(pvk_dec3<4>, PvDec3<4>::lds()));
-        HIPCHK(allow_lds((pvk_enc_bwd<4, PV_MODE_TRAIN, 0, 4>), 4 * lds_enc_bwd(e->Wp)));
+        PV_ATTR_MT(4)
     }
+#undef PV_ATTR_MT
     switch (e->NWB) {
         case 1: PV_ATTR(1) break;
         case 2: PV_ATTR(2) break;
@@ -983,6 +992,53 @@ int run_chunk(pvae_engine* e, int row_offset, int nrows, int n_batch, int c, boo
     return multi_tile_train(e, row_offset, d_out3, last ? 4 : 2);
 }
 
+// evaluation of up to 32 T rows of a batch of n_batch (validation batches above 32 rows): one read of the wide weights for all
+// of them -- first-layer forward of T tiles, the chain's forward on 2 T workers, the read-only decoder pass, the loss scalars
+template <int T>
+int multi_tile_eval_launches(pvae_engine* e, int row_offset, int nrows, int n_batch, float* d_out3) {
+    int rc;
+    const int R = 32 * T, nR = R * e->Wp;
+    hipLaunchKernelGGL(pvk_tile_begin, dim3(1), dim3(64), 0, e->stream, e->st, nrows, 1.f / (float)n_batch, 0);
+    if ((rc = launch_check(e, "tile_begin"))) return rc;
+    {
+        Timer t(e, C_GATHER);
+        hipLaunchKernelGGL(pvk_gather_transpose, dim3(((e->nblk + 1) / 2 + 3) / 4, T), dim3(256), 0, e->stream, e->geno, e->row_bytes,
+                           e->d_rows, e->st, row_offset, e->nblk, e->Xt, e->Xr);
+        if ((rc = launch_check(e, "gather_transpose"))) return rc;
+    }
+    {
+        Timer t(e, C_ENC_FWD);
+        hipLaunchKernelGGL((pvk_enc_fwd<4, T>), dim3(e->encf_mt_wgs), dim3(256), kEncFwdLds, e->stream, e->W1.w, e->geno, e->row_bytes,
+                           e->d_rows, e->st, row_offset, e->nblk, e->ngrp, e->encpart, e->ts4, (const uint64_t*)e->Xr);
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(nR)), dim3(256), 0, e->stream, e->encpart, e->encf_mt_wgs, nR, 0.5f,
+                           e->P, (const float*)nullptr, (float*)nullptr);
+        if ((rc = launch_check(e, "enc_fwd"))) return rc;
+    }
+    if ((rc = shard_allreduce(e, 0, R))) return rc;
+    {
+        Timer t(e, C_NARROW_FWD);
+        if ((rc = narrow_fused_fwd(e, false, false, T))) return rc;
+    }
+    {
+        Timer t(e, C_DEC);
+        hipLaunchKernelGGL(pvk_dec_eval_mt<T>, dim3(e->dece_mt_wgs), dim3(256), lds_dec_eval_mt(T), e->stream, (const float*)e->Vout.w,
+                           (const float*)e->cout.w, (const float*)e->g[e->D - 1], (const uint64_t*)e->Xt, e->nblk, (int)e->L,
+                           (const PvStep*)e->st, e->losspart, e->ts4);
+        hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(0)), dim3(256), 0, e->stream, e->dgpart, e->dece_mt_wgs, 0, 1.0f,
+                           e->xch1, e->losspart, e->xch1 + nR);
+        if ((rc = launch_check(e, "dec_eval"))) return rc;
+    }
+    if ((rc = shard_allreduce(e, 1, R))) return rc;
+    hipLaunchKernelGGL(pvk_narrow_bwd<PV_MODE_TRAIN>, dim3(1), dim3(PVN_THREADS), pvn_lds_bwd(), e->stream, (const PvBwdOp*)e->d_bwd_ops,
+                       e->n_bwd_ops, e->xch1, e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st, e->adam, d_out3, 0,
+                       (int)PVN_WORKERS * T);
+    return launch_check(e, "loss");
+}
+int multi_tile_eval(pvae_engine* e, int row_offset, int nrows, int n_batch, float* d_out3) {
+    return e->T == 2 ? multi_tile_eval_launches<2>(e, row_offset, nrows, n_batch, d_out3)
+                     : multi_tile_eval_launches<4>(e, row_offset, nrows, n_batch, d_out3);
+}
+
 // one 32-row tile of a larger batch (rows already on the device at d_rows[row_offset..]): forward, loss part,
 // gradients stored (first tile) or added (later tiles) in the g buffers; the LAST tile of a train step runs the
 // training kernels, which add the dumped gradients to their own before Adam (PV_MODE_TRAIN_ACC) -- every wide
@@ -1023,6 +1079,25 @@ int full_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, 
         return fetch_out3(e, out3);
     }
     const int R = 32 * e->T;
+    if (mode == 1 && e->T > 1 && e->fused_narrow) {  // evaluation: one read of the wide weights per 32 T rows
+        const int nc = (n + R - 1) / R;
+        if ((rc = ensure_loss(e, nc))) return rc;
+        for (int c = 0; c < nc; ++c) {
+            const int nb = std::min(R, n - R * c);
+            if ((rc = begin_batch(e, rows + R * c, nb, eps ? eps + (size_t)R * c * e->K : nullptr, false, R))) return rc;
+            if ((rc = multi_tile_eval(e, 0, nb, n, e->d_loss + 3 * c))) return rc;
+        }
+        std::vector<float> hc((size_t)nc * 3);
+        HIPCHK(hipMemcpyAsync(hc.data(), e->d_loss, hc.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (out3)
+            for (int k = 0; k < 3; ++k) {
+                float a = 0.f;
+                for (int c = 0; c < nc; ++c) a += hc[(size_t)c * 3 + k];
+                out3[k] = a;
+            }
+        return 0;
+    }
     const bool chunks = mode == 0 && e->T > 1;  // above 32 T rows: one weight pass per 32 T rows
     const int nt = chunks ? (n + R - 1) / R : (n + 31) / 32;
     if (chunks) {
@@ -1305,6 +1380,7 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
         }
         // width 128: a workgroup's four waves are the block columns of one subtile slot
         if (e->T > 1) e->encf_mt_wgs = (int)balance(e->nblk, (int64_t)cus * 2);
+        if (e->T > 1) e->dece_mt_wgs = (int)((balance(e->nblk, (int64_t)cus * 2 * 4) + 3) / 4);
         if (e->ngrp == 1) e->dec_wgs = (int)((balance(e->nblk, (int64_t)cus * o_dec * 4) + 3) / 4);
         else {  // a workgroup takes dec_grp_waves / ngrp SNP blocks per iteration
             const int bpi = dec_grp_waves(e->ngrp) / e->ngrp;
@@ -1584,6 +1660,15 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
                     if (nc == 1) rc = multi_tile_train(e, base + s * B, slot);
                     else rc = run_chunk(e, base + s * B + R * c, std::min(R, nb - R * c), nb, c, c == nc - 1, slot + 3 * c);
                     if (rc) return rc;
+                }
+                continue;
+            }
+            if (phase == 1 && e->T > 1 && nb > 32 && e->fused_narrow) {  // validation: one read of the wide weights per 32 T rows
+                const int R = 32 * e->T, nc = (nb + R - 1) / R;
+                for (int c = 0; c < nc; ++c) {
+                    hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, R * e->K, e->cfg.seed, e->d_counter);
+                    if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
+                    if ((rc = multi_tile_eval(e, base + s * B + R * c, std::min(R, nb - R * c), nb, slot + 3 * c))) return rc;
                 }
                 continue;
             }

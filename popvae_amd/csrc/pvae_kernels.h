@@ -1704,6 +1704,68 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wide decoder, evaluation pass (loss only: validation batches, popvae.py:496) for T row tiles, width 128: pvk_dec<4, 0, ..>'s
+// read-only sweep with the subtile held in registers while every tile's logits and BCE terms are formed -- V is read once
+// per 32 T rows.  One wave per subtile, round-robin; LDS: the T g tiles.  losspart[workgroup] = summed BCE of its SNPs.
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(256) void pvk_dec_eval_mt(const float* __restrict__ V, const float* __restrict__ cb,
+                                                       const float* __restrict__ g, const uint64_t* __restrict__ Xt, int nblk, int L,
+                                                       const PvStep* st, float* __restrict__ losspart, int ts) {
+    constexpr int WP = 128, LDG = WP + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* g_s = smem;  // [32 T][LDG]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int gw = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    const int nrows = st->nrows;
+    const float inv_b = st->inv_b;
+    const int bce_probs = PV_BCE_MODE(st);
+    for (int i = tid; i < 32 * T * WP; i += 256) g_s[(i / WP) * LDG + (i % WP)] = g[i];
+    __syncthreads();
+    float lossacc = 0.f;
+    for (int blk = gw; blk < nblk; blk += nwaves) {
+        asm volatile("" ::: "memory");  // keep the g operand reads inside the loop (see pvk_dec)
+        const f32x4* tV = reinterpret_cast<const f32x4*>(V) + (int64_t)blk * ts + lane;
+        f32x4 vv[4][4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vv[w][q] = __builtin_nontemporal_load(tV + (w * 4 + q) * 64);
+        const int l = blk * 32 + c;
+        const bool lvalid = l < L;
+        const float bias = cb[lvalid ? l : L - 1];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (32 * t >= nrows) break;  // wave-uniform: tiles beyond the batch
+            const uint64_t xs = Xt[((int64_t)t * nblk + blk) * 32 + c] >> (8 * h);
+            const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
+            const float* gt = g_s + t * 32 * LDG;
+            f32x16 a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[c * LDG + w * 32 + PV_ROW(r, h)], vv[w][r >> 2][r & 3], a, 0, 0, 0);
+            float dbias = 0.f;
+            pv_sigmoid_bce(bce_probs, (blk * 32 + 32 <= L) && (32 * t + 32 <= nrows), true, a, bias, lo, hi, h, 32 * t, nrows, lvalid,
+                           inv_b, lossacc, dbias);
+        }
+    }
+    __syncthreads();
+    lossacc += __shfl_xor(lossacc, 1);
+    lossacc += __shfl_xor(lossacc, 2);
+    lossacc += __shfl_xor(lossacc, 4);
+    lossacc += __shfl_xor(lossacc, 8);
+    lossacc += __shfl_xor(lossacc, 16);
+    lossacc += __shfl_xor(lossacc, 32);
+    if (lane == 0) smem[wave] = lossacc;
+    __syncthreads();
+    if (tid == 0) losspart[blockIdx.x] = ((smem[0] + smem[1]) + smem[2]) + smem[3];
+}
+
+// ---------------------------------------------------------------------------------------------
 // decoder.predict (scripts/popvae_decoder_tests_HGDP.py:156): probs[b][l] = sigmoid(g_D[b] . V[:, l] + c[l]) for
 // b < nrows.  One wave per SNP block, looping over the unit groups; read-only pass over V (HBM-bound,
 // 4 B per wide parameter + 4 B per output).

@@ -131,10 +131,12 @@ def test_full_size_batches_in_one_weight_pass(name, L, D, B, n):
     e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=B, seed=0)
     e.load_genotypes(_pack(codes))
     e.set_weights(w)
+    leval, _, _ = e.eval_step(rows, eps)   # the read-only pass over 32 T rows at a time (pvk_dec_eval_mt)
     loss, recon, kl = e.train_step(rows, eps)
     w64 = [x.astype(np.float64) for x in w]
     c = O.forward(w64, codes[rows] * 0.5, eps.astype(np.float64), D, K)
     grads = O.backward(w64, c, D, K)
+    assert abs(leval - c["loss"]) <= RTOL * abs(c["loss"]), (leval, c["loss"])
     assert abs(loss - c["loss"]) <= RTOL * abs(c["loss"]), (loss, c["loss"])
     assert abs(recon - c["recon"].mean()) <= RTOL * abs(c["recon"].mean())
     del c, w64

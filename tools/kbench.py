@@ -49,11 +49,11 @@ for k in ("gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd"):
         extra = f"  {algo[k] / a / 1e6:8.0f} GB/s" if k in algo else ""
         print(f"  {k:11s} {a * 1e3:9.1f} us x {n / steps:.0f}{extra}")
 print(f"  sum/step    {tot * 1e3:9.1f} us")
-vr = rows[:8 * 32].reshape(8, 32)
+vr = np.resize(rows, 8 * B).reshape(8, B)  # validation batches have the batch size too
 e.set_timing(False)
 e.synchronize()
 t0 = time.perf_counter()
 for r in vr:
     e.eval_step(r, None, want_loss=False)
 e.synchronize()
-print(f"  eval step   {(time.perf_counter() - t0) / 8 * 1e3:.3f} ms")
+print(f"  eval step   {(time.perf_counter() - t0) / 8 * 1e3:.3f} ms ({B} rows)")
