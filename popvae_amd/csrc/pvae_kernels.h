@@ -1500,7 +1500,10 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
             cm = mC[lc];
             cv = vC[lc];
         }
-        f32x4 mq[CPW][4], vq[CPW][4];
+        // what the update of this wave's columns reads besides V: the moments (Adam), the dump (accumulate variants)
+        constexpr int PER = MODE == PV_MODE_GRAD ? 1 : MODE == PV_MODE_TRAIN_ACC ? 3 : 2;
+        constexpr int NREQ = PER * 4 * CPW, RSTEP = 64 / NREQ;  // one request every RSTEP matrix instructions of the dg product
+        f32x4 mq[CPW][4], vq[CPW][4], gq[CPW][4];
         const f32x4* tVn = reinterpret_cast<const f32x4*>(V) + (int64_t)nb * ts + lane;
         PV_D3(0);
         const uint64_t xs = xw >> (8 * h);
@@ -1551,20 +1554,26 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
             const float* vt = sub_s + (w % T) * G::WAVE_F + 4 * 1024 + (w / T) * (32 * 33);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (MODE != PV_MODE_GRAD && r % (16 / (2 * CPW)) == 0) {  // the moments of the columns this wave updates (t, t + T, ...): 8 CPW requests
-                    const int j = (w * 16 + r) / (16 / (2 * CPW));  // 0 .. 8 CPW - 1
-                    const int k = j / 8, q = (j >> 1) & 3;
+                if ((w * 16 + r) % RSTEP == 0 && (w * 16 + r) / RSTEP < NREQ) {  // columns t, t + T, ... of this wave
+                    const int j = (w * 16 + r) / RSTEP, kq = j / PER, what = j % PER, k = kq / 4, q = kq & 3;
                     const int64_t o = tb + ((t + k * T) * 4 + q) * 64;
-                    if (j & 1) vq[k][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vV) + o);
-                    else mq[k][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mV) + o);
+                    const int64_t go = (int64_t)blk * (4 * 256) + ((t + k * T) * 4 + q) * 64 + lane;  // dumps are plain tiles
+                    if (MODE == PV_MODE_GRAD) gq[k][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mV2) + go);
+                    else if (what == 0) mq[k][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mV) + o);
+                    else if (what == 1) vq[k][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vV) + o);
+                    else gq[k][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gV) + go);
                 }
                 dg[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(dt[c * 33 + PV_ROW(r, h)], vt[c * 33 + PV_ROW(r, h)], dg[w], 0, 0, 0);
             }
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
+            int nreq = 0;  // requests that belong to matrix instructions 4 i .. 4 i + 3
+#pragma unroll
+            for (int x = 4 * i; x < 4 * i + 4; ++x) nreq += (x % RSTEP == 0 && x / RSTEP < NREQ) ? 1 : 0;
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-            if (i % (2 / CPW) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (nreq == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (nreq == 2) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
         PV_D3(5);
@@ -1612,13 +1621,12 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
                 for (int t2 = 1; t2 < T; ++t2) gsum += frag[q][t2];
                 const int off = (w * 4 + q) * 64;
                 const int64_t goff = (int64_t)blk * (4 * 256) + off + lane;  // gradient dumps are plain tiles
-                if (MODE == PV_MODE_GRAD) {
-                    f32x4* dump = reinterpret_cast<f32x4*>(mV2) + goff;
-                    if (acc_grads) gsum += __builtin_nontemporal_load(dump);
-                    __builtin_nontemporal_store(gsum, dump);
+                if (MODE == PV_MODE_GRAD) {  // (the old dump was requested whether it counts or not: no branch in the dg phase)
+                    if (acc_grads) gsum += gq[k][q];
+                    __builtin_nontemporal_store(gsum, reinterpret_cast<f32x4*>(mV2) + goff);
                     continue;
                 }
-                if (MODE == PV_MODE_TRAIN_ACC) gsum += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gV) + goff);
+                if (MODE == PV_MODE_TRAIN_ACC) gsum += gq[k][q];
                 f32x4 wq = vv[w][q], m4 = mq[k][q], v4 = vq[k][q];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {

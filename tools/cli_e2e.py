@@ -22,7 +22,13 @@ write_popvae_cache(infile, dc, np.array([f"s{i:04d}" for i in range(N)], dtype=o
 print(f"cache written in {time.perf_counter() - t0:.1f} s ({os.path.getsize(infile) / 1e6:.0f} MB)", flush=True)
 out = os.path.join(d, "run")
 t0 = time.perf_counter()
-rc = cli.main(["--infile", infile, "--out", out, "--seed", "42"] + extra)
+if os.environ.get("PROFILE"):  # where the host side of the run spends its time
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    rc = pr.runcall(cli.main, ["--infile", infile, "--out", out, "--seed", "42"] + extra)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(int(os.environ["PROFILE"]))
+else:
+    rc = cli.main(["--infile", infile, "--out", out, "--seed", "42"] + extra)
 wall = time.perf_counter() - t0
 hist = np.loadtxt(out + "_history.txt", skiprows=1)
 lat = [r.split("\t") for r in open(out + "_latent_coords.txt").read().splitlines()[1:]]
