@@ -1866,16 +1866,21 @@ __device__ __forceinline__ void pvn_adam_unit(const PvBwdOp* __restrict__ ops, i
 // while the chip streams), which was the tail of the kernel at small shapes.
 // T = 32-row tiles of the device pass: dpre is [32 T][ldp], Xt holds T word arrays of nblk * 32 entries one after the other, and
 // dW sums over the tiles before the ONE Adam update (a batch above 32 rows in one weight pass; the fused forward needs T == 1).
-template <int NWB, int FUSE, int T>
+template <int NWB, int FUSE, int T, int MODE = PV_MODE_TRAIN>
 __device__ __forceinline__ void pv_enc_bwd_train(const float* __restrict__ W1, const float* __restrict__ mW,
                                                  const float* __restrict__ vW, float* __restrict__ W1o, float* __restrict__ mWo,
                                                  float* __restrict__ vWo, const float* __restrict__ dpre, int ldp,
                                                  const uint64_t* __restrict__ Xt, int nblk, int ngrp, const PvStep* st, PvAdam adam,
                                                  const uint8_t* __restrict__ geno, int64_t row_bytes, const int* __restrict__ rows,
                                                  int next_off, int next_n, float* __restrict__ fpart, int ts,
-                                                 const PvBwdOp* __restrict__ adam_ops, int adam_units, float* smem) {
+                                                 const PvBwdOp* __restrict__ adam_ops, int adam_units, float* smem,
+                                                 const float* __restrict__ gW = nullptr) {
+    // MODE (chunks of a batch above 32 T rows): PV_MODE_GRAD stores / adds (PvStep.acc) 0.5 dW into the dump mWo (plain tiles) and
+    // reads no weights at all; PV_MODE_TRAIN_ACC adds the dump gW to this pass's gradient before Adam.
     constexpr int WG_UNITS = NWB * 32;
     static_assert(T == 1 || FUSE == 0, "the fused forward rides on one-tile passes only");
+    static_assert(MODE == PV_MODE_TRAIN || FUSE == 0, "the fused forward rides on plain training passes only");
+    const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, h = lane >> 5;
     int bx = blockIdx.x, nwg = gridDim.x;
     if (adam_ops) {
@@ -1893,17 +1898,23 @@ __device__ __forceinline__ void pv_enc_bwd_train(const float* __restrict__ W1, c
     const int slot = gw / NWB, w = gw - slot * NWB;
     const int nslots = (nwg / ngrp) * 4 / NWB;  // the host sizes the grid so that this divides
     const float alpha = st->alpha;
-    struct Block { f32x4 w[4], m[4], v[4]; };
+    struct Block { f32x4 w[4], m[4], v[4], g[4]; };  // (members a MODE does not touch cost nothing)
     auto request = [&](Block& bk, int blk_) {
         const int64_t o = ((int64_t)blk_ * ngrp + grp) * ts + w * 256 + lane;
+        const int64_t go = ((int64_t)blk_ * ngrp + grp) * (NWB * 256) + w * 256 + lane;  // gradient dumps are plain tiles
         const f32x4* tW = reinterpret_cast<const f32x4*>(W1) + o;
         const f32x4* tM = reinterpret_cast<const f32x4*>(mW) + o;
         const f32x4* tV = reinterpret_cast<const f32x4*>(vW) + o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (MODE == PV_MODE_GRAD) {
+                if (acc_grads) bk.g[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mWo) + go + q * 64);
+                continue;
+            }
             bk.w[q] = __builtin_nontemporal_load(tW + q * 64);
             bk.m[q] = __builtin_nontemporal_load(tM + q * 64);
             bk.v[q] = __builtin_nontemporal_load(tV + q * 64);
+            if (MODE == PV_MODE_TRAIN_ACC) bk.g[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gW) + go + q * 64);
         }
     };
     const uint8_t* nrow = nullptr;  // FUSE: lane c's sample of the next batch
@@ -1956,11 +1967,18 @@ __device__ __forceinline__ void pv_enc_bwd_train(const float* __restrict__ W1, c
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (MODE == PV_MODE_GRAD) {
+                f32x4 gq = {0.5f * dw[q * 4 + 0], 0.5f * dw[q * 4 + 1], 0.5f * dw[q * 4 + 2], 0.5f * dw[q * 4 + 3]};
+                if (acc_grads) gq += cur.g[q];
+                __builtin_nontemporal_store(gq, reinterpret_cast<f32x4*>(mWo) + ((int64_t)blk * ngrp + grp) * (NWB * 256) + w * 256 +
+                                                    lane + q * 64);
+                continue;
+            }
             f32x4 wq = cur.w[q], mq = cur.m[q], vq = cur.v[q];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float w_ = wq[e], m_ = mq[e], v_ = vq[e];
-                pv_adam(w_, m_, v_, 0.5f * dw[q * 4 + e], alpha, adam);
+                pv_adam(w_, m_, v_, MODE == PV_MODE_TRAIN_ACC ? 0.5f * dw[q * 4 + e] + cur.g[q][e] : 0.5f * dw[q * 4 + e], alpha, adam);
                 wq[e] = w_;
                 mq[e] = m_;
                 vq[e] = v_;
@@ -2009,15 +2027,15 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [ngrp][32][WG_UNITS]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
     PV_WT(1, 0);
-    if constexpr (MODE == PV_MODE_TRAIN) {
-        pv_enc_bwd_train<NWB, FUSE, T>(W1, mW, vW, W1o, mWo, vWo, dpre, ldp, Xt, nblk, ngrp, st, adam, geno, row_bytes, rows, next_off,
-                                    next_n, fpart, ts, adam_ops, adam_units, smem);
+    if constexpr (MODE == PV_MODE_TRAIN || T > 1) {  // several row tiles: the block-column sweep in every mode
+        pv_enc_bwd_train<NWB, FUSE, T, MODE>(W1, mW, vW, W1o, mWo, vWo, dpre, ldp, Xt, nblk, ngrp, st, adam, geno, row_bytes, rows,
+                                          next_off, next_n, fpart, ts, adam_ops, adam_units, smem, gW);
         PV_WT(1, 3);
         return;
     }
     // Gradient dump (MODE_GRAD) and Adam on this pass + the dump (MODE_TRAIN_ACC): tiles of a batch above 32 rows.  One
     // wave per subtile, round-robin; a workgroup stays on one unit group (gridDim.x is a multiple of ngrp).
-    // T row tiles (chunks of a batch above 32 T rows): dpre is [32 T][ldp], Xt T word arrays, dW sums over the tiles.
+    // (T == 1 here: passes over several row tiles take the block-column sweep above in every mode)
     static_assert(MODE == PV_MODE_TRAIN || FUSE == 0, "fused forward: plain training pass only");
     const int grp = blockIdx.x % ngrp;
     const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / ngrp) * 4 + wave), nslots = (gridDim.x / ngrp) * 4;
@@ -2043,9 +2061,7 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
         f32x4* oW = reinterpret_cast<f32x4*>(W1o) + t * ts;
         f32x4* oM = reinterpret_cast<f32x4*>(mWo) + t * (MODE == PV_MODE_GRAD ? (int64_t)(NWB * 256) : (int64_t)ts);
         f32x4* oV = reinterpret_cast<f32x4*>(vWo) + t * ts;
-        // (T > 2: the block columns one at a time -- unrolled, the compiler keeps all 16 T codes and the LDS operands of four
-        // columns live and spills 100-260 registers)
-#pragma unroll(T > 2 ? 1 : NWB)
+#pragma unroll
         for (int w = 0; w < NWB; ++w) {
             f32x16 dw;
 #pragma unroll
