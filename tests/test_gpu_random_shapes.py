@@ -1,0 +1,146 @@
+"""Random-shape tests on the GPU (PVAE_FUZZ_CASES cases each, 12 by default; 60-80 were run when they were written):
+  * the two ways a batch above 32 rows is stepped at width <= 128 -- multi-tile kernels against 32-row tiles with gradient dumps;
+  * the C-side epoch loop against stepwise calls at batch size 32 (bit-identical weights and moments);
+  * one training step against the float64 oracle (loss, first moments = (1 - beta_1) * gradient) on one tile, several tiles, chunks,
+    both narrow paths.
+First block: same injected noise -> losses and evaluation losses to 1e-5, Adam's first and second moments after two steps to 1e-5 of
+each tensor's largest entry (the weights themselves are not compared entry by entry: where the true gradient is ~0, Adam turns its
+rounding noise into a step of up to lr)."""
+import os
+
+import numpy as np
+import pytest
+
+from popvae_amd import engine, prep
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = int(os.environ.get("PVAE_FUZZ_CASES", "12"))
+
+
+def _case(seed):
+    g = np.random.default_rng(1000 + seed)
+    L = int(g.choice([33, 64, 95, 200, 777, 1500, 4000, 9000]))
+    W = int(g.choice([32, 64, 96, 128]))
+    D = int(g.integers(1, 5))
+    K = int(g.choice([2, 3, 8]))
+    B = int(g.choice([33, 48, 64, 65, 100, 128, 129, 200, 300]))
+    n = int(g.integers(max(1, B // 3), B + 1))
+    return g, L, W, D, K, B, n
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_multi_tile_equals_tile_path(seed, monkeypatch):
+    g, L, W, D, K, B, n = _case(seed)
+    N = B + 10
+    f = np.clip(g.beta(.5, .5, L), .02, .98)
+    dc = g.binomial(2, f, size=(N, L)) * 0.5
+    packed = prep.pack_dc(dc)
+    steps = [(g.choice(N, m, replace=False).astype(np.int32), g.normal(size=(m, K)).astype(np.float32)) for m in (n, B, max(1, n // 2))]
+    outs = []
+    for tiles in (False, True):
+        if tiles:
+            monkeypatch.setenv("PVAE_NO_MULTITILE", "1")
+        else:
+            monkeypatch.delenv("PVAE_NO_MULTITILE", raising=False)
+        e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=B, seed=3)
+        e.load_genotypes(packed)
+        e.init_weights(11)
+        res = []
+        for rows, eps in steps[:2]:
+            res.append(e.train_step(rows, eps)[0])
+        res.append(e.eval_step(*steps[2])[0])
+        res.append(e.eval_step(*steps[1])[0])
+        outs.append((res, e.get_moments(0) + e.get_moments(1), e.get_weights()))
+        e.close()
+    (ra, ma, wa), (rb, mb, wb) = outs
+    tag = (seed, L, W, D, K, B, n)
+    for a, b in zip(ra, rb):
+        assert np.isfinite(a) and abs(a - b) <= 1e-5 * abs(b), (tag, ra, rb)
+    for i, (a, b) in enumerate(zip(ma, mb)):
+        assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-30), (tag, "moment", i, np.abs(a - b).max(), np.abs(b).max())
+    for i, (a, b) in enumerate(zip(wa, wb)):
+        # two Adam steps of lr = 1e-3: the bulk of the entries agree to float32 rounding of the update
+        assert np.median(np.abs(a - b)) <= 1e-7 and np.abs(a - b).max() <= 2.1e-3, (tag, i, np.abs(a - b).max())
+
+
+def _case_epoch(seed):
+    g = np.random.default_rng(5000 + seed)
+    L = int(g.choice([31, 64, 100, 333, 1000, 2500, 7000]))
+    W = int(g.choice([32, 64, 80, 128, 200, 256, 512]))
+    D = int(g.integers(1, 7))
+    K = int(g.choice([2, 5, 16]))
+    n_train = int(g.integers(1, 130))
+    n_val = int(g.integers(0, 50))
+    return g, L, W, D, K, n_train, n_val
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_epoch_loop_equals_stepwise_on_random_shapes(seed):
+    """pvae_train_epoch (C-side loop: step head, next batch's first-layer forward fused into the wide encoder backward, ragged last
+    batch, validation batches) against pvae_train_step / pvae_eval_step calls on the same rows and the same engine noise stream, at
+    batch size 32 on random shapes of both narrow paths: same epoch losses, same weights and Adam moments after two epochs."""
+    g, L, W, D, K, n_train, n_val = _case_epoch(seed)
+    N = n_train + n_val + 3
+    f = np.clip(g.beta(.5, .5, L), .02, .98)
+    packed = prep.pack_dc(g.binomial(2, f, size=(N, L)) * 0.5)
+    perm = g.permutation(N)[:n_train].astype(np.int32)
+    val = np.arange(N - n_val, N, dtype=np.int32)
+    res = []
+    for mode in ("epoch", "steps"):
+        e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=32, seed=5)
+        e.load_genotypes(packed)
+        e.init_weights(3)
+        for _ in range(2):
+            if mode == "epoch":
+                loss, vloss = e.train_epoch(perm, val)
+            else:
+                tl = [e.train_step(perm[i:i + 32])[0] for i in range(0, n_train, 32)]
+                vl = [e.eval_step(val[i:i + 32])[0] for i in range(0, n_val, 32)]
+                loss, vloss = float(np.mean(np.array(tl, np.float32))), (float(np.mean(np.array(vl, np.float32))) if vl else float("nan"))
+        res.append((loss, vloss, e.get_weights(), e.get_moments(0) + e.get_moments(1)))
+        e.close()
+    (la, va, wa, ma), (lb, vb, wb, mb) = res
+    tag = (seed, L, W, D, K, n_train, n_val)
+    assert np.isfinite(la) and abs(la - lb) <= 1e-6 * abs(lb), (tag, la, lb)
+    assert (np.isnan(va) and np.isnan(vb)) or abs(va - vb) <= 1e-6 * abs(vb), (tag, va, vb)
+    for i, (a, b) in enumerate(zip(wa, wb)):
+        assert np.array_equal(a, b), (tag, "w", i, np.abs(a - b).max())
+    for i, (a, b) in enumerate(zip(ma, mb)):
+        assert np.array_equal(a, b), (tag, "m/v", i, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_training_pass_against_oracle_on_random_shapes(seed):
+    """One training step from zero moments on a random shape (both narrow paths, one tile / several tiles / chunks): loss against the
+    float64 oracle and every tensor's first moment = (1 - beta_1) * the oracle's gradient, to 1e-4 of the tensor's largest entry."""
+    from oracle import popvae_oracle as O
+    g = np.random.default_rng(9000 + seed)
+    L = int(g.choice([31, 64, 100, 333, 1000, 2500]))
+    W = int(g.choice([32, 64, 80, 128, 200, 256, 512]))
+    D = int(g.integers(1, 6))
+    K = int(g.choice([2, 5, 16]))
+    B = int(g.choice([32, 32, 48, 64, 128, 200]))
+    n = int(g.integers(1, B + 1))
+    N = B + 5
+    f = np.clip(g.beta(.5, .5, L), .02, .98)
+    dc = g.binomial(2, f, size=(N, L)) * 0.5
+    w = O.init_weights(L, W, D, K, seed=seed, dtype=np.float32)
+    for t in w:
+        if t.ndim == 1:
+            t += g.normal(0, 0.05, t.shape).astype(np.float32)
+    rows = g.choice(N, n, replace=False).astype(np.int32)
+    eps = g.normal(size=(n, K)).astype(np.float32)
+    e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=B, seed=0)
+    e.load_genotypes(prep.pack_dc(dc))
+    e.set_weights(w)
+    loss, recon, kl = e.train_step(rows, eps)
+    w64 = [x.astype(np.float64) for x in w]
+    c = O.forward(w64, dc[rows], eps.astype(np.float64), D, K)
+    grads = O.backward(w64, c, D, K)
+    tag = (seed, L, W, D, K, B, n)
+    assert abs(loss - c["loss"]) <= 1e-4 * abs(c["loss"]), (tag, loss, c["loss"])
+    for i, (a, b) in enumerate(zip(e.get_moments(0), grads)):
+        err = np.abs(a.astype(np.float64) * 10.0 - b).max() / max(np.abs(b).max(), 1e-30)
+        assert err <= 1e-4, (tag, i, err)
+    e.close()
