@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     auto mma = [&](const f32x4 (&wv)[4], const uint64_t (&xw)[T]) {
-#ifdef PV_EXP_NOMMA
+#ifdef PV_EXP_NOMMA  // bound-finder builds: the kernel without its matrix instructions (NOMMA) / without its loads (NOLOAD)
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[t][0] += (float)(uint32_t)xw[t] + wv[0][0] + wv[1][1] + wv[2][2] + wv[3][3];
 #else
