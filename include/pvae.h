@@ -163,6 +163,19 @@ int pvae_comm_info(pvae_engine* e, int32_t* nranks, int32_t* rank);
 int pvae_comm_allreduce(pvae_engine* e, int which);
 int pvae_comm_destroy(pvae_engine* e);
 
+/* One-shot exchange among the ranks' processes instead of the two RCCL all-reduces of a step (SURVEY 8e "tuned path"; opt-in:
+ * PVAE_COMM=p2p in popvae_amd/dist.py; no counterpart in the reference, which is single-GPU).  Every rank owns an inbox in
+ * fine-grained device memory; pvae_p2p_prepare allocates it and returns its 64-byte hipIpc handle, the host carries the handles
+ * of all ranks to every rank (rank order, 64 bytes each), pvae_p2p_connect maps the peers' inboxes; from then on the ordinary
+ * calls (pvae_train_epoch, pvae_train_step, pvae_encode, pvae_comm_allreduce ...) exchange through one kernel per exchange point
+ * (pvk_p2p_allreduce: 8-byte {sequence, value} words written into every rank's inbox, summed in rank order).  Waits are bounded:
+ * an exchange that gives up fills the buffer with NaN and pvae_p2p_status reports it.  At most 16 ranks.  Rehearsed with two
+ * processes on one GPU (tests/test_gpu_dist.py); between devices it has not run yet. */
+int pvae_p2p_prepare(pvae_engine* e, char* handle64);
+int pvae_p2p_connect(pvae_engine* e, const char* handles /* world x 64 bytes */);
+int pvae_p2p_status(pvae_engine* e, int32_t* gave_up);
+int pvae_p2p_disconnect(pvae_engine* e);
+
 /* measurement hook: average device time (ms) of the last call's kernels by name, via hipEvents on the
  * engine stream; names: "enc_fwd", "dec", "enc_bwd", "narrow_fwd", "narrow_bwd", "gather", and "xch0" / "xch1" = the two
  * all-reduces of a step on the engine-owned communicator */

@@ -205,6 +205,7 @@ def main(argv=None):
         from .dist import ShardedEngine
         eng = ShardedEngine(n_snps=n_snps, width=width, depth=depth, latent_dim=args.latent_dim,
                             batch_size=args.batch_size, seed=eng_seed, device_id=device_id)
+        log(f"SNP axis sharded over {world} ranks; exchanges: {eng.comm_report()['note']}")
         eng.load_genotypes(packed)
         eng.init_weights(eng_seed)
         eng.eng.set_bce_mode(args.bce_mode)

@@ -135,6 +135,13 @@ struct pvae_engine {
     // SNP-axis sharding with the engine's own RCCL communicator (pvae_comm_init): the two all-reduces of a step are
     // enqueued on the engine's stream between the stages, no host code and no cross-stream events in between
     void* comm = nullptr;
+    // one-shot exchange among processes (pvae_p2p_*): this rank's inbox, the peers' mappings of theirs, the exchange counter
+    unsigned long long* p2p_inbox = nullptr;
+    void* p2p_peer[PV_P2P_MAX_WORLD] = {};
+    int64_t p2p_words = 0;
+    unsigned p2p_seq = 0;
+    int* p2p_status = nullptr;
+    bool p2p = false;
     // staged API: rows whose first-layer partial sums the last pvae_stage_c_next left in encpart (empty = none)
     std::vector<int32_t> promised_rows;
     // pinned host staging ring for the per-step API (rows + eps), so that async copies never read caller memory
@@ -422,13 +429,25 @@ PvRccl* rccl() {
 }
 // SUM all-reduce of exchange buffer `which` over the shards, in place, on the engine's stream; nothing to do on one rank
 // rows: rows of the device pass whose partial sums are exchanged (32; 32 T in a multi-tile pass)
+static inline bool has_comm(const pvae_engine* e) { return e->comm || e->p2p; }
 int shard_allreduce(pvae_engine* e, int which, int rows = 32) {
-    if (e->cfg.world == 1 && !e->comm) return 0;  // a one-rank communicator (rehearsal on one GPU) is still driven
-    if (!e->comm) return set_err(e, -5, "world > 1 without a communicator: call pvae_comm_init, or drive the step through "
-                                        "pvae_stage_a/b/c with all-reduces in between");
+    if (e->cfg.world == 1 && !has_comm(e)) return 0;  // a one-rank communicator (rehearsal on one GPU) is still driven
+    if (!has_comm(e)) return set_err(e, -5, "world > 1 without a communicator: call pvae_comm_init, or drive the step through "
+                                            "pvae_stage_a/b/c with all-reduces in between");
     float* buf = which == 0 ? e->P : e->xch1;
     const size_t n = which == 0 ? (size_t)rows * e->Wp : (size_t)rows * e->Wp + 32;  // dg rows, then the loss sums
     Timer t(e, which == 0 ? C_XCH0 : C_XCH1);
+    if (e->p2p) {
+        if ((int64_t)n > e->p2p_words) return set_err(e, -12, "exchange of %zu floats, inbox slots hold %lld", n, (long long)e->p2p_words);
+        PvPeers peers;
+        for (int r = 0; r < e->cfg.world; ++r)
+            peers.inbox[r] = r == e->cfg.rank ? e->p2p_inbox : reinterpret_cast<unsigned long long*>(e->p2p_peer[r]);
+        ++e->p2p_seq;
+        if (e->p2p_seq == 0) ++e->p2p_seq;  // 0 is what an untouched inbox holds
+        hipLaunchKernelGGL(pvk_p2p_allreduce, dim3(std::min<size_t>(16, (n + 1023) / 1024)), dim3(256), 0, e->stream, buf, (int)n, peers,
+                           e->cfg.rank, e->cfg.world, e->p2p_seq, e->p2p_words, e->p2p_status);
+        return launch_check(e, "p2p_allreduce");
+    }
     const int rc = rccl()->AllReduce(buf, buf, n, 7 /* ncclFloat32 */, 0 /* ncclSum */, e->comm, e->stream);
     if (rc) return set_err(e, -12, "ncclAllReduce: %s", rccl()->GetErrorString(rc));
     return 0;
@@ -1058,7 +1077,7 @@ int run_tile(pvae_engine* e, int row_offset, int nrows, int n_batch, int tile, i
 int full_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3, int mode) {
     e->promised_rows.clear();
     int rc;
-    if (e->cfg.world != 1 && !e->comm)
+    if (e->cfg.world != 1 && !has_comm(e))
         return set_err(e, -5, "world > 1: call pvae_comm_init first, or drive the step through pvae_stage_a/b/c with "
                               "all-reduces in between");
     if (n <= 0 || n > e->cfg.batch_size) return set_err(e, -2, "batch of %d rows (batch_size %d)", n, e->cfg.batch_size);
@@ -1453,6 +1472,8 @@ int pvae_destroy(pvae_engine* e) {
     hipSetDevice(e->dev);
     if (e->own_stream) hipStreamSynchronize(e->own_stream);
     pvae_comm_destroy(e);
+    if (e->p2p_inbox) hipFree(e->p2p_inbox);
+    if (e->p2p_status) hipFree(e->p2p_status);
     for_each_buf(e, [](Buf3& b) { free3(b); });
     for (auto& d : e->enc) { hipFree(d.wf); hipFree(d.wb); }
     for (auto& d : e->dec) { hipFree(d.wf); hipFree(d.wb); }
@@ -1604,7 +1625,7 @@ int pvae_train_step_noalloc(pvae_engine* e, const int32_t* rows, int32_t n, cons
     if (n <= 0 || n > 32)
         return set_err(e, -2, "pvae_train_step_noalloc takes one device pass of 1..32 rows (got %d); larger batches run as "
                               "tiles with gradient dumps that pvae_train_step allocates on first use", n);
-    if (e->cfg.world != 1 || e->comm)
+    if (e->cfg.world != 1 || has_comm(e))
         return set_err(e, -5, "pvae_train_step_noalloc: SNP-sharded engines exchange through RCCL, which allocates");
     if (e->timing) return set_err(e, -6, "pvae_train_step_noalloc: switch event timing off first (events are created on demand)");
     auto al = [](size_t floats) { return (floats + 63) / 64 * 64; };  // 256-byte steps
@@ -1629,7 +1650,7 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
                      float* loss, float* val_loss) {
     e->promised_rows.clear();
     int rc;
-    if (e->cfg.world != 1 && !e->comm) return set_err(e, -5, "world > 1: call pvae_comm_init first, or use the staged API");
+    if (e->cfg.world != 1 && !has_comm(e)) return set_err(e, -5, "world > 1: call pvae_comm_init first, or use the staged API");
     if (!e->geno) return set_err(e, -3, "no genotypes loaded (pvae_load_genotypes)");
     if (n_train <= 0) return set_err(e, -2, "empty training set");
     const int B = e->cfg.batch_size;
@@ -1748,7 +1769,7 @@ int pvae_encode(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
                 float* z) {
     e->promised_rows.clear();
     int rc;
-    if (e->cfg.world != 1 && !e->comm)
+    if (e->cfg.world != 1 && !has_comm(e))
         return set_err(e, -5, "world > 1: call pvae_comm_init first, or use pvae_stage_a + all-reduce + pvae_stage_encode");
     if (n <= 0) return set_err(e, -2, "encode of %d rows", n);
     const int B = 32, nbat = (n + B - 1) / B;
@@ -2009,7 +2030,63 @@ int pvae_comm_allreduce(pvae_engine* e, int which) {
     if (which != 0 && which != 1) return set_err(e, -2, "exchange buffer %d", which);
     return shard_allreduce(e, which);
 }
+// One-shot exchange among the ranks' processes (opt-in alternative to the RCCL all-reduces; kernel: pvk_p2p_allreduce).
+int pvae_p2p_prepare(pvae_engine* e, char* handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+    if (e->cfg.world < 1 || e->cfg.world > PV_P2P_MAX_WORLD) return set_err(e, -2, "one-shot exchange: world %d (at most %d)", e->cfg.world, PV_P2P_MAX_WORLD);
+    HIPCHK(hipSetDevice(e->dev));
+    if (!e->p2p_inbox) {
+        e->p2p_words = (int64_t)32 * e->T * e->Wp + 32;  // the largest exchange: dg of a pass + the loss sums
+        const size_t bytes = (size_t)2 * e->cfg.world * e->p2p_words * sizeof(unsigned long long);
+        HIPCHK(hipExtMallocWithFlags((void**)&e->p2p_inbox, bytes, hipDeviceMallocFinegrained));
+        HIPCHK(hipMemset(e->p2p_inbox, 0, bytes));
+        HIPCHK(hipMalloc(&e->p2p_status, sizeof(int)));
+        HIPCHK(hipMemset(e->p2p_status, 0, sizeof(int)));
+        HIPCHK(hipDeviceSynchronize());
+    }
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, e->p2p_inbox));
+    memcpy(handle64, &h, 64);
+    return 0;
+}
+int pvae_p2p_connect(pvae_engine* e, const char* handles) {
+    if (!e->p2p_inbox) return set_err(e, -12, "pvae_p2p_connect before pvae_p2p_prepare");
+    if (e->p2p) return set_err(e, -12, "one-shot exchange already connected");
+    HIPCHK(hipSetDevice(e->dev));
+    for (int r = 0; r < e->cfg.world; ++r) {
+        if (r == e->cfg.rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)64 * r, 64);
+        const hipError_t rc = hipIpcOpenMemHandle(&e->p2p_peer[r], h, hipIpcMemLazyEnablePeerAccess);
+        if (rc != hipSuccess) {
+            for (int q = 0; q < r; ++q)
+                if (e->p2p_peer[q]) { hipIpcCloseMemHandle(e->p2p_peer[q]); e->p2p_peer[q] = nullptr; }
+            return set_err(e, -12, "hipIpcOpenMemHandle (rank %d's inbox): %s", r, hipGetErrorString(rc));
+        }
+    }
+    e->p2p = true;
+    return 0;
+}
+int pvae_p2p_status(pvae_engine* e, int32_t* gave_up) {
+    int st = 0;
+    if (e->p2p_status) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpy(&st, e->p2p_status, sizeof(int), hipMemcpyDeviceToHost));
+    }
+    if (gave_up) *gave_up = st;
+    return 0;
+}
+int pvae_p2p_disconnect(pvae_engine* e) {
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (int r = 0; r < PV_P2P_MAX_WORLD; ++r)
+        if (e->p2p_peer[r]) { hipIpcCloseMemHandle(e->p2p_peer[r]); e->p2p_peer[r] = nullptr; }
+    e->p2p = false;
+    // (the inbox stays allocated until pvae_destroy: a peer may still have it mapped)
+    return 0;
+}
+
 int pvae_comm_destroy(pvae_engine* e) {
+    pvae_p2p_disconnect(e);
     if (e->comm) {
         hipStreamSynchronize(e->stream);
         rccl()->CommDestroy(e->comm);

@@ -2103,6 +2103,50 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// One-shot all-reduce of an exchange buffer among the ranks of an SNP-sharded model (SURVEY 8e "tuned path"; opt-in,
+// pvae_p2p_*): every rank owns an inbox in fine-grained device memory that its peers have mapped (hipIpc; over xGMI on a node),
+// [parity 2][sender world][words].  A rank writes its n floats into EVERY rank's inbox (its own included) as 8-byte words
+// {sequence number, value}: a word arrives whole, so no fence and no separate flag is needed (the idea of RCCL's LL protocol);
+// then it waits per word for the sequence number of this exchange and sums the senders in RANK ORDER -- every rank adds the
+// same numbers in the same order, so the replicated narrow stack stays bit-identical across ranks.  Two parities: a peer can be
+// at most one exchange ahead (it needs this rank's words of exchange k + 1, sent only after exchange k was read), so the slot
+// of exchange k + 2 is free when it writes it.  Waits are bounded; a wait that gives up poisons the buffer with NaN and raises
+// *status (loudly wrong, not hung).  Vector stores / loads with system scope only.
+// ---------------------------------------------------------------------------------------------
+#define PV_P2P_MAX_WORLD 16
+struct PvPeers { unsigned long long* inbox[PV_P2P_MAX_WORLD]; };
+__global__ __launch_bounds__(256) void pvk_p2p_allreduce(float* __restrict__ buf, int n, PvPeers peers, int rank, int world,
+                                                         unsigned seq, int64_t words, int* __restrict__ status) {
+    const int64_t slot = ((int64_t)(seq & 1) * world) * words;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    for (int i = tid; i < n; i += nth) {
+        const unsigned long long word = ((unsigned long long)seq << 32) | __float_as_uint(buf[i]);
+        for (int p = 0; p < world; ++p)
+            __hip_atomic_store(peers.inbox[p] + slot + (int64_t)rank * words + i, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    for (int i = tid; i < n; i += nth) {
+        float sum = 0.f;
+        bool ok = true;
+        for (int r = 0; r < world && ok; ++r) {
+            const unsigned long long* src = peers.inbox[rank] + slot + (int64_t)r * words + i;
+            unsigned long long w = 0;
+            ok = false;
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned)(w >> 32) == seq) { ok = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            sum += __uint_as_float((unsigned)w);
+        }
+        if (!ok) {
+            sum = __builtin_nanf("");
+            *status = 1;
+        }
+        buf[i] = sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // N(0,1) draws for the reparameterisation (K3: TF's Philox stream is not reproducible outside TF, any
 // standard-normal generator is admissible).  Philox4x32-10 + Box-Muller, counter = (call, index).
 // ---------------------------------------------------------------------------------------------

@@ -115,6 +115,8 @@ class ShardedEngine:
         if os.environ.get("PVAE_COMM", "rccl").lower() == "torch" or not hasattr(self.eng, "comm_init"):
             self.comm_note += " (PVAE_COMM=torch)" if hasattr(self.eng, "comm_init") else ""
             return False
+        if os.environ.get("PVAE_COMM", "rccl").lower() == "p2p" and hasattr(self.eng, "p2p_prepare"):
+            return self._init_p2p()
         import socket
         try:
             uid = str(self._torch.cuda.get_device_properties(self.device_id).uuid)
@@ -166,11 +168,52 @@ class ShardedEngine:
         self.comm_note = f"engine-owned RCCL communicator, rank {me} of {nr} (ncclCommCount)"
         return True
 
+    def _init_p2p(self):
+        """One-shot exchange among the ranks' processes (PVAE_COMM=p2p; include/pvae.h pvae_p2p_*), set up by agreement like the
+        RCCL communicator: every rank allocates its inbox and hands out the hipIpc handle, torch.distributed carries the handles,
+        every rank maps its peers' inboxes, one exchange of (rank + 1) checks the lot.  Any failure on any rank leaves the
+        host-staged path in place on all of them.  Ranks may share a device (rehearsals on a one-GPU box)."""
+        dist = self._dist
+        handle = None
+        try:
+            handle = self.eng.p2p_prepare()
+        except Exception:
+            handle = None
+        if not self._agree(handle is not None):
+            self.comm_note += " (one-shot exchange: inbox / hipIpc handle failed on some rank)"
+            return False
+        handles = [None] * self.world
+        dist.all_gather_object(handles, handle, group=self.pg)
+        ok = True
+        try:
+            self.eng.p2p_connect(handles)
+            n = self.eng.exchange_buffer(0)[1]
+            for rep in range(3):  # both parities of the inbox, and one reuse
+                self.eng.exchange_write(0, np.full(n, self.rank + 1 + rep, np.float32))
+                self.eng.comm_allreduce(0)
+                got = self.eng.exchange_read(0)
+                ok = ok and bool(np.all(got == np.float32(self.world * (self.world + 1) // 2 + rep * self.world)))
+            ok = ok and not self.eng.p2p_gave_up()
+        except Exception:
+            ok = False
+        if not self._agree(ok):
+            try:
+                self.eng.p2p_disconnect()
+            except Exception:
+                pass
+            self.comm_note += " (one-shot exchange: self-test failed on some rank)"
+            return False
+        self.comm_note = f"one-shot exchange through hipIpc-mapped inboxes, rank {self.rank} of {self.world}"
+        self._p2p = True
+        return True
+
     def comm_report(self):
         """For bench.py's --gpus N line: which exchange path runs and what RCCL itself says about the communicator."""
         out = {"path": "native" if self.native else ("host-staged" if (self.world > 1 or self.force_collectives) else "none"),
                "note": self.comm_note, "comm_nranks": None}
-        if self.native:
+        if self.native and getattr(self, "_p2p", False):
+            out["path"], out["comm_nranks"] = "p2p", self.world
+        elif self.native:
             out["comm_nranks"] = self.eng.comm_info()[0]
         return out
 

@@ -22,6 +22,7 @@ ENGINE_SYMBOLS = [
     "pvae_decode", "pvae_pca_gram", "pvae_snapshot_best", "pvae_restore_best", "pvae_exchange_buffer", "pvae_exchange_copy", "pvae_stage_a", "pvae_stage_b",
     "pvae_stage_c", "pvae_stage_c_next", "pvae_stage_encode", "pvae_set_timing", "pvae_get_timing", "pvae_set_timing_only",
     "pvae_comm_available", "pvae_comm_info", "pvae_comm_unique_id", "pvae_comm_init", "pvae_comm_allreduce", "pvae_comm_destroy",
+    "pvae_p2p_prepare", "pvae_p2p_connect", "pvae_p2p_status", "pvae_p2p_disconnect",
 ]
 
 
@@ -91,6 +92,10 @@ def lib():
         L.pvae_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
         L.pvae_comm_allreduce.argtypes = [vp, C.c_int]
         L.pvae_comm_destroy.argtypes = [vp]
+        L.pvae_p2p_prepare.argtypes = [vp, C.c_char_p]
+        L.pvae_p2p_connect.argtypes = [vp, C.c_char_p]
+        L.pvae_p2p_status.argtypes = [vp, C.POINTER(C.c_int32)]
+        L.pvae_p2p_disconnect.argtypes = [vp]
         L.pvae_get_timing.argtypes = [vp, C.c_char_p, _fopt, C.POINTER(i64)]
         _lib = L
     return _lib
@@ -355,6 +360,26 @@ class Engine:
 
     def comm_allreduce(self, which):
         self._ck(lib().pvae_comm_allreduce(self._h, which))
+
+    # one-shot exchange among the ranks' processes (opt-in alternative to the RCCL all-reduces, include/pvae.h)
+    def p2p_prepare(self):
+        """Allocate this rank's inbox; returns its 64-byte hipIpc handle (to be carried to every rank by the host)."""
+        buf = C.create_string_buffer(64)
+        self._ck(lib().pvae_p2p_prepare(self._h, buf))
+        return buf.raw
+
+    def p2p_connect(self, handles):
+        """handles: the ranks' 64-byte handles in rank order; maps the peers' inboxes and switches the exchanges over."""
+        blob = b"".join(handles)
+        self._ck(lib().pvae_p2p_connect(self._h, blob))
+
+    def p2p_gave_up(self):
+        st = C.c_int32(0)
+        self._ck(lib().pvae_p2p_status(self._h, C.byref(st)))
+        return bool(st.value)
+
+    def p2p_disconnect(self):
+        self._ck(lib().pvae_p2p_disconnect(self._h))
 
     # -- measurement -----------------------------------------------------------------------------
     def set_timing(self, on, only=None):

@@ -23,8 +23,8 @@ def _run(cmd, env=None, timeout=280):
     return p
 
 
-def _launch2(args, port):
-    env = dict(os.environ, PVAE_DIST_BACKEND="gloo")
+def _launch2(args, port, **extra_env):
+    env = dict(os.environ, PVAE_DIST_BACKEND="gloo", **extra_env)
     return _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                  "127.0.0.1", "--master-port", str(port), "popvae.py"] + args, env=env)
 
@@ -70,3 +70,23 @@ def test_two_rank_grid_search(tmp_path):
     assert [r.split(",")[:2] for r in rows[1:]] == [["32", "2"], ["32", "3"], ["64", "2"], ["64", "3"]]  # width-major
     assert all(np.isfinite(float(r.split(",")[2])) for r in rows[1:])
     assert os.path.getsize(out + "_latent_coords.txt") > 0
+
+
+def test_two_rank_cli_one_shot_exchange_matches_one_rank(tmp_path):
+    """The same comparison with PVAE_COMM=p2p: the C-side epoch loop of both ranks (fused next-batch forward, validation, encode)
+    with the two exchanges of every step going through the ranks' hipIpc-mapped inboxes (pvk_p2p_allreduce)."""
+    common = ["--infile", VCF, "--seed", "42", "--max_epochs", "25", "--patience", "120"]
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    _run([sys.executable, "popvae.py", "--out", one] + common)
+    port = 29600 + int(np.random.default_rng().integers(0, 2000))
+    p = _launch2(["--out", two] + common, port, PVAE_COMM="p2p")
+    assert "one-shot exchange" in p.stdout + p.stderr, (p.stdout[-1500:], p.stderr[-1500:])
+    _, a = _table(one + "_latent_coords.txt")
+    _, b = _table(two + "_latent_coords.txt")
+    assert [r[-1] for r in a] == [r[-1] for r in b] and len(a) == 95
+    A = np.array([[float(x) for x in r[:4]] for r in a])
+    B = np.array([[float(x) for x in r[:4]] for r in b])
+    assert np.abs(A - B).max() <= 2e-3 * max(1.0, np.abs(A).max()), np.abs(A - B).max()
+    H1 = np.loadtxt(one + "_history.txt", skiprows=1)
+    H2 = np.loadtxt(two + "_history.txt", skiprows=1)
+    assert H1.shape == H2.shape and np.allclose(H1, H2, rtol=1e-4)

@@ -35,3 +35,24 @@ def test_two_rank_snp_sharding_on_one_gpu(tmp_path, monkeypatch, dims, comm):
             assert "share a device" in r["comm"]["note"], r["comm"]
     ref = H.reference_run(dims)
     H.compare(res, ref, dims, rtol=1e-4, wtol=2e-2 * 4e-3)
+
+
+@pytest.mark.parametrize("dims", [(40, 1000, 128, 3, 2), (40, 700, 256, 2, 2)])
+def test_two_rank_one_shot_exchange_on_one_gpu(tmp_path, monkeypatch, dims):
+    """PVAE_COMM=p2p: the two exchanges of a step go through pvk_p2p_allreduce -- every rank writes its partial into every rank's
+    hipIpc-mapped inbox and sums the senders in rank order -- instead of RCCL.  Two PROCESSES on the one GPU of the test box (on a
+    node the same mappings cross xGMI): handles carried by torch.distributed, the agreed self-test, then the whole sharded protocol
+    with the engine's own calls (train_step, encode, eval_step ... exchange inside the engine) against the unsharded oracle."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("PVAE_COMM", "p2p")
+    out = str(tmp_path / "res")
+    port = 29500 + int(np.random.default_rng().integers(0, 2000))
+    mp.spawn(H.sharded_worker, args=(2, port, out, True, dims), nprocs=2, join=True)
+    res = [np.load(out + f".{r}.npy", allow_pickle=True)[0] for r in range(2)]
+    for r in res:
+        assert r["native"] is True and r["comm"]["path"] == "p2p" and r["comm"]["comm_nranks"] == 2, r["comm"]
+    # both ranks hold bit-identical replicated tensors (the senders are summed in rank order on every rank)
+    for a, b in zip(res[0]["weights"][1:-2], res[1]["weights"][1:-2]):
+        assert np.array_equal(a, b)
+    ref = H.reference_run(dims)
+    H.compare(res, ref, dims, rtol=1e-4, wtol=2e-2 * 4e-3)
