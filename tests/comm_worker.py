@@ -38,20 +38,26 @@ for with_comm in (False, True):
     e.close()
 # batches above 32 rows: the two exchanges of a pass carry all its row tiles (48 rows: one pass of two tiles; 60 rows at
 # batch_size 160 would be one pass of four; validation batches: 32-row tiles), one Adam pass per batch
+# ("p2p": the one-shot exchange with this rank as its only peer -- its own inbox, both parities, exchanges of 32 T rows)
 for B in (48, 160):
     big = []
-    for with_comm in (False, True):
+    for with_comm in (False, True, "p2p"):
         e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=B, seed=5)
-        if with_comm:
+        if with_comm == "p2p":
+            e.p2p_connect([e.p2p_prepare()])
+        elif with_comm:
             e.comm_init(engine.Engine.comm_unique_id())
         e.load_genotypes(prep.pack_dc(dc))
         e.set_weights([x.astype(np.float32) for x in w])
         res = [e.train_epoch(perm, val), e.train_step(perm[:min(B, 70)]), e.eval_step(val)]
+        if with_comm == "p2p":
+            assert not e.p2p_gave_up()
         big.append((res, e.get_weights()))
         e.close()
-    assert big[0][0] == big[1][0], (B, big)
-    for a, b in zip(big[0][1], big[1][1]):
-        assert np.array_equal(a, b)
+    for other in big[1:]:
+        assert big[0][0] == other[0], (B, big[0][0], other[0])
+        for a, b in zip(big[0][1], other[1]):
+            assert np.array_equal(a, b)
 (ra, wa, ma), (rb, wb, mb) = outs
 assert ra == rb, (ra, rb)
 for a, b in zip(wa, wb):
