@@ -116,7 +116,9 @@ class ShardedEngine:
             self.comm_note += " (PVAE_COMM=torch)" if hasattr(self.eng, "comm_init") else ""
             return False
         if os.environ.get("PVAE_COMM", "rccl").lower() == "p2p" and hasattr(self.eng, "p2p_prepare"):
-            return self._init_p2p()
+            if self._init_p2p():
+                return True
+            # (not available on every rank: carry on with the RCCL communicator, then the host-staged path)
         import socket
         try:
             uid = str(self._torch.cuda.get_device_properties(self.device_id).uuid)
