@@ -344,7 +344,8 @@ int setup_kernel_attrs(pvae_engine* e) {
     HIPCHK(allow_lds((pvk_enc_bwd<4, PV_MODE_TRAIN, 0, TT>), TT * lds_enc_bwd(e->Wp)));                     \
     HIPCHK(allow_lds((pvk_enc_bwd<4, PV_MODE_GRAD, 0, TT>), TT * lds_enc_bwd(e->Wp)));                      \
     HIPCHK(allow_lds((pvk_enc_bwd<4, PV_MODE_TRAIN_ACC, 0, TT>), TT * lds_enc_bwd(e->Wp)));                 \
-    HIPCHK(allow_lds(pvk_dec_eval_mt<TT>, lds_dec_eval_mt(TT)));
+    HIPCHK(allow_lds((pvk_dec_eval_mt<TT, 0>), lds_dec_eval_mt(TT)));                                      \
+    HIPCHK(allow_lds((pvk_dec_eval_mt<TT, 1>), lds_dec_eval_mt(TT)));
     if (e->T == 2) {
         PV_ATTR_MT(2)
     } else if (e->T == 4) {
@@ -1013,8 +1014,10 @@ int run_chunk(pvae_engine* e, int row_offset, int nrows, int n_batch, int c, boo
 
 // evaluation of up to 32 T rows of a batch of n_batch (validation batches above 32 rows): one read of the wide weights for all
 // of them -- first-layer forward of T tiles, the chain's forward on 2 T workers, the read-only decoder pass, the loss scalars
+// nbatches > 0: the rows are nbatches validation batches of 32 rows (the last one may be short), each with a loss of its own ->
+// d_out3[3 t ..]; nbatches == 0: one batch of nrows rows out of n_batch (1 / n_batch weights its loss part)
 template <int T>
-int multi_tile_eval_launches(pvae_engine* e, int row_offset, int nrows, int n_batch, float* d_out3) {
+int multi_tile_eval_launches(pvae_engine* e, int row_offset, int nrows, int n_batch, float* d_out3, int nbatches = 0) {
     int rc;
     const int R = 32 * T, nR = R * e->Wp;
     hipLaunchKernelGGL(pvk_tile_begin, dim3(1), dim3(64), 0, e->stream, e->st, nrows, 1.f / (float)n_batch, 0);
@@ -1038,9 +1041,24 @@ int multi_tile_eval_launches(pvae_engine* e, int row_offset, int nrows, int n_ba
         Timer t(e, C_NARROW_FWD);
         if ((rc = narrow_fused_fwd(e, false, false, T))) return rc;
     }
+    if (nbatches > 0) {  // one loss per tile
+        Timer t(e, C_DEC);
+        hipLaunchKernelGGL((pvk_dec_eval_mt<T, 1>), dim3(e->dece_mt_wgs), dim3(256), lds_dec_eval_mt(T), e->stream, (const float*)e->Vout.w,
+                           (const float*)e->cout.w, (const float*)e->g[e->D - 1], (const uint64_t*)e->Xt, e->nblk, (int)e->L,
+                           (const PvStep*)e->st, e->losspart, e->ts4);
+        const bool sharded = e->cfg.world != 1 || has_comm(e);
+        hipLaunchKernelGGL(pvk_loss_tiles, dim3(1), dim3(256), 0, e->stream, (const float*)e->losspart, e->dece_mt_wgs, nbatches,
+                           (const float*)e->kl, (const PvStep*)e->st, e->xch1 + nR, d_out3, sharded ? 1 : 3);
+        if ((rc = launch_check(e, "dec_eval"))) return rc;
+        if (!sharded) return 0;
+        if ((rc = shard_allreduce(e, 1, R))) return rc;
+        hipLaunchKernelGGL(pvk_loss_tiles, dim3(1), dim3(256), 0, e->stream, (const float*)e->losspart, e->dece_mt_wgs, nbatches,
+                           (const float*)e->kl, (const PvStep*)e->st, e->xch1 + nR, d_out3, 2);
+        return launch_check(e, "loss");
+    }
     {
         Timer t(e, C_DEC);
-        hipLaunchKernelGGL(pvk_dec_eval_mt<T>, dim3(e->dece_mt_wgs), dim3(256), lds_dec_eval_mt(T), e->stream, (const float*)e->Vout.w,
+        hipLaunchKernelGGL((pvk_dec_eval_mt<T, 0>), dim3(e->dece_mt_wgs), dim3(256), lds_dec_eval_mt(T), e->stream, (const float*)e->Vout.w,
                            (const float*)e->cout.w, (const float*)e->g[e->D - 1], (const uint64_t*)e->Xt, e->nblk, (int)e->L,
                            (const PvStep*)e->st, e->losspart, e->ts4);
         hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(0)), dim3(256), 0, e->stream, e->dgpart, e->dece_mt_wgs, 0, 1.0f,
@@ -1053,9 +1071,9 @@ int multi_tile_eval_launches(pvae_engine* e, int row_offset, int nrows, int n_ba
                        (int)PVN_WORKERS * T);
     return launch_check(e, "loss");
 }
-int multi_tile_eval(pvae_engine* e, int row_offset, int nrows, int n_batch, float* d_out3) {
-    return e->T == 2 ? multi_tile_eval_launches<2>(e, row_offset, nrows, n_batch, d_out3)
-                     : multi_tile_eval_launches<4>(e, row_offset, nrows, n_batch, d_out3);
+int multi_tile_eval(pvae_engine* e, int row_offset, int nrows, int n_batch, float* d_out3, int nbatches = 0) {
+    return e->T == 2 ? multi_tile_eval_launches<2>(e, row_offset, nrows, n_batch, d_out3, nbatches)
+                     : multi_tile_eval_launches<4>(e, row_offset, nrows, n_batch, d_out3, nbatches);
 }
 
 // one 32-row tile of a larger batch (rows already on the device at d_rows[row_offset..]): forward, loss part,
@@ -1328,9 +1346,11 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     // batches of 33 .. 128 rows in one weight pass, larger ones in chunks of 128 rows (gradients dumped between the chunks):
     // width 128 (four block columns, the fused chain).  Under SNP sharding the two exchanges of such a pass carry 32 T rows
     // (engine-owned communicator; the host-driven staged calls stay at 32 rows per call and ignore T)
-    if (cfg->batch_size > 32 && e->Wp == 128 && 2 * e->D + 2 <= PVN_MAXOPS &&
+    // Batch sizes up to 32 get four tiles as well: their validation batches go through the read-only kernels four at a time
+    // (pvae_train_epoch); the training path of such an engine never sees more than one tile.
+    if (e->Wp == 128 && 2 * e->D + 2 <= PVN_MAXOPS &&
         !getenv("PVAE_NO_FUSED_NARROW") && !getenv("PVAE_NO_DEC2") && !getenv("PVAE_NO_MULTITILE"))
-        e->T = cfg->batch_size <= 64 ? 2 : 4;
+        e->T = (cfg->batch_size > 32 && cfg->batch_size <= 64) ? 2 : 4;
     const int64_t R = 32 * (int64_t)e->T;  // rows the activation buffers hold
     const int64_t act_n = R * (int64_t)std::max(e->Wp, std::max(e->Kh, e->Kz));
     CK(allocf(e, &e->P, R * e->Wp));
@@ -1438,7 +1458,9 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     e->fuse_fwd = !getenv("PVAE_NO_FUSE_FWD");
     CK(allocf(e, &e->dgpart, std::max((int64_t)std::max(e->dec_wgs, e->dec2_wgs) * 32 * e->Wp,
                                       (int64_t)e->dec3_wgs * 32 * e->T * e->Wp)));
-    CK(allocf(e, &e->losspart, (int64_t)std::max(std::max(std::max(e->dec_wgs, e->dec2_wgs), e->dec_eval_wgs), e->dec3_wgs)));
+    // one BCE sum per workgroup of whichever decoder kernel runs; pvk_dec_eval_mt<T, 1> leaves one per workgroup AND row tile
+    CK(allocf(e, &e->losspart, (int64_t)std::max(std::max(std::max(e->dec_wgs, e->dec2_wgs), std::max(e->dec_eval_wgs, e->dec3_wgs)),
+                                                 e->T * e->dece_mt_wgs)));
 
     HK(hipMalloc(&e->st, sizeof(PvStep)));
     PvStep st0{};
@@ -1703,9 +1725,24 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
             }
         }
     }
+    // batch size 32: the validation batches go through the read-only kernels T at a time, each with its own loss (one read
+    // of the wide weights per T batches instead of one per batch)
+    const bool mt_val = tp == 1 && B == 32 && e->T > 1 && e->fused_narrow && st_va > 1 && !getenv("PVAE_NO_MT_VAL");
     for (int phase = 0; phase < 2 && tp == 1; ++phase) {
         const int steps = phase == 0 ? st_tr : st_va;
         if (!steps) continue;
+        if (phase == 1 && mt_val) {
+            for (int s0 = 0; s0 < steps; s0 += e->T) {
+                const int nbt = std::min(e->T, steps - s0), nrows = std::min(32 * nbt, (int)n_val - 32 * s0);
+                for (int t = 0; t < nbt; ++t)  // one draw per batch, as the batch-by-batch path makes them
+                    hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps + (size_t)32 * t * e->K, 32 * e->K, e->cfg.seed,
+                                       e->d_counter);
+                if ((rc = launch_check(e, "gen_eps"))) return rc;
+                if ((rc = multi_tile_eval(e, n_train + 32 * s0, nrows, 32, e->d_loss + 3 * (size_t)(st_tr + s0), nbt))) return rc;
+            }
+            fwd_done = false;
+            continue;
+        }
         int nt = phase == 0 ? n_train : n_val;
         HIPCHK(hipMemcpyAsync(e->d_ntotal, &nt, sizeof(int), hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));  // nt is a stack variable
@@ -1716,7 +1753,7 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
             bool fuse = false;
             if (phase == 0 && e->fuse_fwd) {
                 if (s + 1 < st_tr) { next_off = (s + 1) * B; next_n = std::min(B, n_train - next_off); fuse = true; }
-                else if (st_va > 0) { next_off = n_train; next_n = std::min(B, (int)n_val); fuse = true; }
+                else if (st_va > 0 && !mt_val) { next_off = n_train; next_n = std::min(B, (int)n_val); fuse = true; }
             }
             // per-step scalars + noise + batch gather (+ the sum of the first-layer partial tiles the previous step's wide
             // encoder backward left behind) in one launch

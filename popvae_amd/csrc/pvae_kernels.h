@@ -1716,7 +1716,7 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
 // read-only sweep with the subtile held in registers while every tile's logits and BCE terms are formed -- V is read once
 // per 32 T rows.  One wave per subtile, round-robin; LDS: the T g tiles.  losspart[workgroup] = summed BCE of its SNPs.
 // ---------------------------------------------------------------------------------------------
-template <int T>
+template <int T, int PER_TILE = 0>
 __global__ __launch_bounds__(256) void pvk_dec_eval_mt(const float* __restrict__ V, const float* __restrict__ cb,
                                                        const float* __restrict__ g, const uint64_t* __restrict__ Xt, int nblk, int L,
                                                        const PvStep* st, float* __restrict__ losspart, int ts) {
@@ -1730,7 +1730,12 @@ __global__ __launch_bounds__(256) void pvk_dec_eval_mt(const float* __restrict__
     const int bce_probs = PV_BCE_MODE(st);
     for (int i = tid; i < 32 * T * WP; i += 256) g_s[(i / WP) * LDG + (i % WP)] = g[i];
     __syncthreads();
-    float lossacc = 0.f;
+    // PER_TILE: every row tile is a batch of its own (several validation batches of 32 rows in one pass over V): one BCE sum per
+    // tile, losspart[tile][workgroup]; otherwise the tiles are one batch, losspart[workgroup]
+    constexpr int NL = PER_TILE ? T : 1;
+    float lossacc[NL];
+#pragma unroll
+    for (int t = 0; t < NL; ++t) lossacc[t] = 0.f;
     for (int blk = gw; blk < nblk; blk += nwaves) {
         asm volatile("" ::: "memory");  // keep the g operand reads inside the loop (see pvk_dec)
         const f32x4* tV = reinterpret_cast<const f32x4*>(V) + (int64_t)blk * ts + lane;
@@ -1758,19 +1763,58 @@ __global__ __launch_bounds__(256) void pvk_dec_eval_mt(const float* __restrict__
                     a = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[c * LDG + w * 32 + PV_ROW(r, h)], vv[w][r >> 2][r & 3], a, 0, 0, 0);
             float dbias = 0.f;
             pv_sigmoid_bce(bce_probs, (blk * 32 + 32 <= L) && (32 * t + 32 <= nrows), true, a, bias, lo, hi, h, 32 * t, nrows, lvalid,
-                           inv_b, lossacc, dbias);
+                           inv_b, lossacc[PER_TILE ? t : 0], dbias);
         }
     }
     __syncthreads();
-    lossacc += __shfl_xor(lossacc, 1);
-    lossacc += __shfl_xor(lossacc, 2);
-    lossacc += __shfl_xor(lossacc, 4);
-    lossacc += __shfl_xor(lossacc, 8);
-    lossacc += __shfl_xor(lossacc, 16);
-    lossacc += __shfl_xor(lossacc, 32);
-    if (lane == 0) smem[wave] = lossacc;
+#pragma unroll
+    for (int t = 0; t < NL; ++t) {
+        float v = lossacc[t];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane == 0) smem[t * 4 + wave] = v;
+    }
     __syncthreads();
-    if (tid == 0) losspart[blockIdx.x] = ((smem[0] + smem[1]) + smem[2]) + smem[3];
+    if (tid < NL) losspart[tid * gridDim.x + blockIdx.x] = ((smem[tid * 4] + smem[tid * 4 + 1]) + smem[tid * 4 + 2]) + smem[tid * 4 + 3];
+}
+
+// Loss scalars of up to T validation batches that went through one pass (pvk_dec_eval_mt<T, 1>): batch t = rows 32 t .. of the pass.
+//   stage & 1: recon[t] = sum over the workgroups of losspart[t][.] (fixed order) -> xrecon[t]   (then the shards' all-reduce)
+//   stage & 2: out3[3 t ..] = (recon + kl, recon, kl) / n_t of batch t (popvae.py:423), n_t = its rows
+__global__ __launch_bounds__(256) void pvk_loss_tiles(const float* __restrict__ losspart, int nwg, int ntiles,
+                                                      const float* __restrict__ kl, const PvStep* st, float* __restrict__ xrecon,
+                                                      float* __restrict__ out3, int stage) {
+    __shared__ float sm[256];
+    const int tid = threadIdx.x, t = tid >> 6, lane = tid & 63;  // 64 threads per tile, at most 4 tiles
+    if (stage & 1) {
+        float a = 0.f;
+        if (t < ntiles)
+            for (int p = lane; p < nwg; p += 64) a += losspart[t * nwg + p];
+        sm[tid] = a;
+        __syncthreads();
+        if (lane == 0 && t < ntiles) {
+            float sum = 0.f;
+            for (int i = 0; i < 64; ++i) sum += sm[t * 64 + i];
+            xrecon[t] = sum;
+        }
+        __syncthreads();
+    }
+    if ((stage & 2) && lane == 0 && t < ntiles) {
+        const int n = min(32, st->nrows - 32 * t);
+        if (n > 0) {
+            const float sr = xrecon[t];
+            float sk = 0.f;
+            for (int b = 0; b < n; ++b) sk += kl[32 * t + b];
+            const float inv = 1.f / (float)n;
+            out3[3 * t] = (sr + sk) * inv;
+            out3[3 * t + 1] = sr * inv;
+            out3[3 * t + 2] = sk * inv;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
