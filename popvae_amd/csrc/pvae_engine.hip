@@ -100,6 +100,7 @@ struct pvae_engine {
     int64_t enc_out_cap = 0;   // in batches
     // scratch
     float *encpart = nullptr, *dgpart = nullptr, *losspart = nullptr;
+    int64_t encpart_cap = 0, dgpart_cap = 0, losspart_cap = 0;  // floats allocated: checked against the grids of the multi-tile passes
     float* scratch = nullptr;      // this device's copy of pv_scratch (hipGetSymbolAddress at pvae_create)
     float* h_out3 = nullptr;       // pinned staging of {loss, recon, kl}
     int enc_wgs = 0, dec_wgs = 0, encb_wgs = 0, dec_eval_wgs = 0;
@@ -918,6 +919,10 @@ int multi_tile_launches(pvae_engine* e, int row_offset, float* d_out3, int mode)
                            e->d_rows, e->st, row_offset, e->nblk, e->Xt, e->Xr);
         if ((rc = launch_check(e, "gather_transpose"))) return rc;
     }
+    if ((int64_t)e->encf_mt_wgs * nR > e->encpart_cap || (int64_t)e->dec3_wgs * nR > e->dgpart_cap ||
+        (int64_t)T * e->dece_mt_wgs > e->losspart_cap || e->dec3_wgs > e->losspart_cap)
+        return set_err(e, -6, "multi-tile pass: partial-sum buffers smaller than the grids (%d / %d / %d workgroups)", e->encf_mt_wgs,
+                       e->dec3_wgs, e->dece_mt_wgs);
     {
         Timer t(e, C_ENC_FWD);
         hipLaunchKernelGGL((pvk_enc_fwd<4, T>), dim3(e->encf_mt_wgs), dim3(256), kEncFwdLds, e->stream, e->W1.w, e->geno, e->row_bytes,
@@ -1028,6 +1033,10 @@ int multi_tile_eval_launches(pvae_engine* e, int row_offset, int nrows, int n_ba
                            e->d_rows, e->st, row_offset, e->nblk, e->Xt, e->Xr);
         if ((rc = launch_check(e, "gather_transpose"))) return rc;
     }
+    if ((int64_t)e->encf_mt_wgs * nR > e->encpart_cap || (int64_t)e->dec3_wgs * nR > e->dgpart_cap ||
+        (int64_t)T * e->dece_mt_wgs > e->losspart_cap || e->dec3_wgs > e->losspart_cap)
+        return set_err(e, -6, "multi-tile pass: partial-sum buffers smaller than the grids (%d / %d / %d workgroups)", e->encf_mt_wgs,
+                       e->dec3_wgs, e->dece_mt_wgs);
     {
         Timer t(e, C_ENC_FWD);
         hipLaunchKernelGGL((pvk_enc_fwd<4, T>), dim3(e->encf_mt_wgs), dim3(256), kEncFwdLds, e->stream, e->W1.w, e->geno, e->row_bytes,
@@ -1447,7 +1456,8 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
                     e->enc_wgs, e->dec_wgs, e->encb_wgs, e->dec_eval_wgs);
     }
     e->encpart_floats = (int64_t)e->encb_parts * 32 * e->Wp;  // what a one-tile pass needs (pvae_train_step_noalloc)
-    CK(allocf(e, &e->encpart, (int64_t)std::max(e->encb_parts, e->encf_mt_wgs) * 32 * e->Wp * e->T));
+    e->encpart_cap = (int64_t)std::max(e->encb_parts, e->encf_mt_wgs) * 32 * e->Wp * e->T;
+    CK(allocf(e, &e->encpart, e->encpart_cap));
     if (e->T > 1) {
         hipDeviceProp_t prop2;
         HK(hipGetDeviceProperties(&prop2, e->dev));
@@ -1456,11 +1466,11 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
         e->dec3_wgs = std::max(1, std::min(cus2, (e->nblk + spw - 1) / spw));
     }
     e->fuse_fwd = !getenv("PVAE_NO_FUSE_FWD");
-    CK(allocf(e, &e->dgpart, std::max((int64_t)std::max(e->dec_wgs, e->dec2_wgs) * 32 * e->Wp,
-                                      (int64_t)e->dec3_wgs * 32 * e->T * e->Wp)));
+    e->dgpart_cap = std::max((int64_t)std::max(e->dec_wgs, e->dec2_wgs) * 32 * e->Wp, (int64_t)e->dec3_wgs * 32 * e->T * e->Wp);
+    CK(allocf(e, &e->dgpart, e->dgpart_cap));
     // one BCE sum per workgroup of whichever decoder kernel runs; pvk_dec_eval_mt<T, 1> leaves one per workgroup AND row tile
-    CK(allocf(e, &e->losspart, (int64_t)std::max(std::max(std::max(e->dec_wgs, e->dec2_wgs), std::max(e->dec_eval_wgs, e->dec3_wgs)),
-                                                 e->T * e->dece_mt_wgs)));
+    e->losspart_cap = std::max(std::max(std::max(e->dec_wgs, e->dec2_wgs), std::max(e->dec_eval_wgs, e->dec3_wgs)), e->T * e->dece_mt_wgs);
+    CK(allocf(e, &e->losspart, e->losspart_cap));
 
     HK(hipMalloc(&e->st, sizeof(PvStep)));
     PvStep st0{};
