@@ -97,7 +97,7 @@ struct pvae_engine {
     uint64_t* Xr = nullptr;    // the gathered (untransposed) words of the batch: operand order of pvk_enc_fwd
     float* probs = nullptr;  // decoder.predict staging [32][L], allocated on first pvae_decode
     float* enc_out = nullptr;  // encoder.predict staging: per 32-row batch [32][Kh] heads + [32][Kz] z, read back once
-    int64_t enc_out_cap = 0;   // in batches
+    int64_t enc_out_cap = 0;   // in floats
     // scratch
     float *encpart = nullptr, *dgpart = nullptr, *losspart = nullptr;
     int64_t encpart_cap = 0, dgpart_cap = 0, losspart_cap = 0;  // floats allocated: checked against the grids of the multi-tile passes
@@ -860,7 +860,10 @@ int check_rows(pvae_engine* e, const int32_t* rows, int64_t n) {
 
 // upload rows/eps for a single batch and run pvk_step_begin
 constexpr size_t kSlotBytes = 128 * sizeof(int) + 128 * 64 * sizeof(float);  // 128 rows + their noise at latent_dim <= 64
-int begin_batch(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, bool train, int max_rows = 32) {
+// noise_per_32: draw the engine's noise with one generator call per 32 rows (the calls a batch-by-batch pass over the same rows
+// would make: the stream position after the call does not depend on how many rows went through together)
+int begin_batch(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, bool train, int max_rows = 32,
+                bool noise_per_32 = false) {
     int rc;
     if (n <= 0 || n > e->cfg.batch_size) return set_err(e, -2, "batch of %d rows (batch_size %d)", n, e->cfg.batch_size);
     if (n > max_rows) return set_err(e, -2, "a device pass takes at most %d rows (got %d): larger batches go through pvae_train_step / "
@@ -874,13 +877,17 @@ int begin_batch(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
     memcpy(sl.host, rows, n * sizeof(int));
     if (eps) memcpy(sl.host + 128 * sizeof(int), eps, (size_t)n * e->K * sizeof(float));
     HIPCHK(hipMemcpyAsync(e->d_rows, sl.host, n * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    if (eps)
+    if (eps || noise_per_32)
         hipLaunchKernelGGL(pvk_step_begin, dim3(1), dim3(64), 0, e->stream, e->st, (const int*)nullptr, n, e->cfg.batch_size, 0,
                            train ? 1 : 0, e->adam.b1, e->adam.b2);
     else
         hipLaunchKernelGGL(pvk_step_begin_eps, dim3(1), dim3(1024), 0, e->stream, e->st, (const int*)nullptr, n,
                            e->cfg.batch_size, 0, train ? 1 : 0, e->adam.b1, e->adam.b2, e->eps, max_rows * e->K, e->cfg.seed,
                            e->d_counter);
+    if (!eps && noise_per_32)
+        for (int t = 0; 32 * t < n; ++t)
+            hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps + (size_t)32 * t * e->K, 32 * e->K, e->cfg.seed,
+                               e->d_counter);
     if ((rc = launch_check(e, "step_begin"))) return rc;
     if (eps) {
         HIPCHK(hipMemcpyAsync(e->eps, sl.host + 128 * sizeof(int), (size_t)n * e->K * sizeof(float), hipMemcpyHostToDevice,
@@ -1819,38 +1826,57 @@ int pvae_encode(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
     if (e->cfg.world != 1 && !has_comm(e))
         return set_err(e, -5, "world > 1: call pvae_comm_init first, or use pvae_stage_a + all-reduce + pvae_stage_encode");
     if (n <= 0) return set_err(e, -2, "encode of %d rows", n);
-    const int B = 32, nbat = (n + B - 1) / B;
+    // predict batches are independent of the training batch size: 32 rows per pass, or 32 T where the multi-tile forward exists
+    // (one read of W1 per 32 T rows)
+    const bool mt = e->T > 1 && e->fused_narrow && !getenv("PVAE_NO_MT_ENCODE");
+    const int B = mt ? 32 * e->T : 32, nbat = (n + B - 1) / B;
     // the batches are queued back to back; their outputs collect in a device staging buffer and come back in ONE copy
     // (a device-to-host round trip per batch left the GPU idle for longer than a batch takes)
-    const size_t per = (size_t)32 * (e->Kh + e->Kz);
-    if (nbat > e->enc_out_cap) {
+    const size_t per = (size_t)B * (e->Kh + e->Kz);
+    if ((int64_t)((size_t)nbat * per) > e->enc_out_cap) {
         HIPCHK(hipStreamSynchronize(e->stream));
         if (e->enc_out) hipFree(e->enc_out);
         e->enc_out = nullptr;
         e->enc_out_cap = 0;
         HIPCHK(hipMalloc(&e->enc_out, (size_t)nbat * per * sizeof(float)));
-        e->enc_out_cap = nbat;
+        e->enc_out_cap = (int64_t)((size_t)nbat * per);
     }
     for (int i = 0; i < nbat; ++i) {
         const int i0 = i * B, nb = std::min(B, n - i0);
         const int save = e->cfg.batch_size;
-        e->cfg.batch_size = 32;  // predict batches are independent of the training batch size
-        rc = begin_batch(e, rows + i0, nb, eps ? eps + (size_t)i0 * e->K : nullptr, false);
+        e->cfg.batch_size = B;
+        rc = begin_batch(e, rows + i0, nb, eps ? eps + (size_t)i0 * e->K : nullptr, false, B, mt);
         e->cfg.batch_size = save;
         if (rc) return rc;
-        if ((rc = stage_a(e, 0, false))) return rc;
-        if ((rc = shard_allreduce(e, 0))) return rc;
-        if ((rc = narrow_encoder(e))) return rc;
+        if (mt) {
+            const int nR = B * e->Wp;
+            if ((int64_t)e->encf_mt_wgs * nR > e->encpart_cap) return set_err(e, -6, "encode: partial-sum buffer smaller than the grid");
+#define PV_ENC_MT(TT)                                                                                                              \
+    hipLaunchKernelGGL((pvk_enc_fwd<4, TT>), dim3(e->encf_mt_wgs), dim3(256), kEncFwdLds, e->stream, e->W1.w, e->geno, e->row_bytes, \
+                       e->d_rows, e->st, 0, e->nblk, e->ngrp, e->encpart, e->ts4, (const uint64_t*)nullptr)
+            if (e->T == 2) PV_ENC_MT(2);
+            else PV_ENC_MT(4);
+#undef PV_ENC_MT
+            hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(nR)), dim3(256), 0, e->stream, e->encpart, e->encf_mt_wgs, nR, 0.5f,
+                               e->P, (const float*)nullptr, (float*)nullptr);
+            if ((rc = launch_check(e, "enc_fwd"))) return rc;
+            if ((rc = shard_allreduce(e, 0, B))) return rc;
+            if ((rc = narrow_fused_fwd(e, true, false, e->T))) return rc;
+        } else {
+            if ((rc = stage_a(e, 0, false))) return rc;
+            if ((rc = shard_allreduce(e, 0))) return rc;
+            if ((rc = narrow_encoder(e))) return rc;
+        }
         float* dst = e->enc_out + (size_t)i * per;
-        HIPCHK(hipMemcpyAsync(dst, e->headout, (size_t)32 * e->Kh * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(dst + 32 * e->Kh, e->z, (size_t)32 * e->Kz * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(dst, e->headout, (size_t)B * e->Kh * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(dst + (size_t)B * e->Kh, e->z, (size_t)B * e->Kz * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
     }
     std::vector<float> host((size_t)nbat * per);
     HIPCHK(hipMemcpyAsync(host.data(), e->enc_out, host.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int r = 0; r < n; ++r) {
         const float* ho = host.data() + (size_t)(r / B) * per + (size_t)(r % B) * e->Kh;
-        const float* zz = host.data() + (size_t)(r / B) * per + (size_t)32 * e->Kh + (size_t)(r % B) * e->Kz;
+        const float* zz = host.data() + (size_t)(r / B) * per + (size_t)B * e->Kh + (size_t)(r % B) * e->Kz;
         for (int k = 0; k < e->K; ++k) {
             if (z_mean) z_mean[(size_t)r * e->K + k] = ho[k];
             if (z_log_var) z_log_var[(size_t)r * e->K + k] = ho[e->K + k];
