@@ -14,11 +14,11 @@ import numpy as np  # noqa: E402
 from popvae_amd import engine, prep  # noqa: E402
 from tests.test_gpu_parity import _problem  # noqa: E402
 
-N, L, W, D, K = 80, 3000, 128, 3, 2
+N, L, W, D, K = 120, 3000, 128, 3, 2
 dc, w = _problem(N, L, W, D, K, seed=31)
 g = np.random.default_rng(3)
 perm = g.permutation(70).astype(np.int32)
-val = np.arange(70, 80, dtype=np.int32)
+val = np.arange(70, 120, dtype=np.int32)  # two validation batches: they share one pass of the read-only multi-tile kernels
 outs = []
 for with_comm in (False, True):
     e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=32, seed=5)
@@ -32,7 +32,7 @@ for with_comm in (False, True):
     e.set_weights([x.astype(np.float32) for x in w])
     res = [e.train_epoch(perm, val) for _ in range(2)]
     res.append(e.train_step(perm[:32]))
-    res.append(e.eval_step(val))
+    res.append(e.eval_step(val[:32]))
     mu, _, _ = e.encode(np.arange(N, dtype=np.int32))
     outs.append((res, e.get_weights(), mu))
     e.close()
@@ -49,7 +49,7 @@ for B in (48, 160):
             e.comm_init(engine.Engine.comm_unique_id())
         e.load_genotypes(prep.pack_dc(dc))
         e.set_weights([x.astype(np.float32) for x in w])
-        res = [e.train_epoch(perm, val), e.train_step(perm[:min(B, 70)]), e.eval_step(val)]
+        res = [e.train_epoch(perm, val), e.train_step(perm[:min(B, 70)]), e.eval_step(val[:min(B, 50)])]
         if with_comm == "p2p":
             assert not e.p2p_gave_up()
         big.append((res, e.get_weights()))
