@@ -74,8 +74,10 @@ def test_two_rank_grid_search(tmp_path):
 
 def test_two_rank_cli_one_shot_exchange_matches_one_rank(tmp_path):
     """The same comparison with PVAE_COMM=p2p: the C-side epoch loop of both ranks (fused next-batch forward, validation, encode)
-    with the two exchanges of every step going through the ranks' hipIpc-mapped inboxes (pvk_p2p_allreduce)."""
-    common = ["--infile", VCF, "--seed", "42", "--max_epochs", "25", "--patience", "120"]
+    with the two exchanges of every step going through the ranks' hipIpc-mapped inboxes (pvk_p2p_allreduce).  --train_prop 0.5
+    leaves 47 validation samples: two validation batches, which share one pass of the multi-tile read-only kernels (exchanges of
+    128 rows)."""
+    common = ["--infile", VCF, "--seed", "42", "--max_epochs", "25", "--patience", "120", "--train_prop", "0.5"]
     one, two = str(tmp_path / "one"), str(tmp_path / "two")
     _run([sys.executable, "popvae.py", "--out", one] + common)
     port = 29600 + int(np.random.default_rng().integers(0, 2000))
