@@ -288,9 +288,11 @@ def main():
             "data": "synthetic" if backend == "nccl" else f"synthetic; REHEARSAL over {backend}, ranks share GPUs: not a measurement",
             "config": {"workload": f"{args.workload}: {N} samples x {L} SNPs, depth {D}, width {W}, latent {K}, "
                                    f"batch {B}, fp32 weights + fused Keras-Adam (lr {args.lr:g})",
-                       "parallelism": (f"snp-shard x{world}, " + ("all-reduces enqueued by the engine (own RCCL communicator)"
-                                                                   if native else "host-driven all-reduces (torch.distributed)"))
-                       if sharded else "single GPU"},
+                       "parallelism": (f"snp-shard x{world}, " + {
+                           "native": "all-reduces enqueued by the engine (own RCCL communicator)",
+                           "p2p": "one-shot exchange kernels enqueued by the engine (hipIpc-mapped inboxes, no RCCL)",
+                           "host-staged": "host-driven, host-staged all-reduces (torch.distributed)",
+                           "none": "no exchange"}[step_engine.comm_report()["path"]]) if sharded else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "pvk_dec2 (fused wide decoder: logits+sigmoid+BCE+dlogits+dV+Adam; pvk_dec_grp above width 128)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,

@@ -91,13 +91,28 @@ def load_genotypes(infile, rng, save_allele_counts=False, log=print):
     return packed, n_snps, samples
 
 
+def test_infile():
+    """The genotypes --test runs on (popvae.py:175-180): data/pabu/pabu_test_genotypes.vcf relative to the working directory,
+    as in the reference; where that file is absent, the copy of the same fixture this repository keeps (gzip-compressed)
+    under tests/golden/."""
+    ref = os.path.join("data", "pabu", "pabu_test_genotypes.vcf")
+    if os.path.exists(ref):
+        return ref
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    alt = os.path.join(here, "tests", "golden", "pabu_test_genotypes.vcf.gz")
+    if os.path.exists(alt):
+        return alt
+    raise SystemExit(f"--test: neither {ref} nor {alt} exists")
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     depth_range = np.array([int(x) for x in re.split(",", args.depth_range)])
     width_range = np.array([int(x) for x in re.split(",", args.width_range)])
 
     if args.test:  # popvae.py:175-180
-        rc = subprocess.run([sys.executable, os.path.abspath(sys.argv[0]), "--infile", "data/pabu/pabu_test_genotypes.vcf",
+        os.makedirs("out", exist_ok=True)  # (the reference ships an empty out/ directory)
+        rc = subprocess.run([sys.executable, os.path.abspath(sys.argv[0]), "--infile", test_infile(),
                              "--out", "out/pabu_test", "--seed", "42"]).returncode
         raise SystemExit(rc)
     if args.plot and args.metadata is None:

@@ -141,6 +141,8 @@ struct pvae_engine {
     void* p2p_peer[PV_P2P_MAX_WORLD] = {};
     int64_t p2p_words = 0;
     unsigned p2p_seq = 0;
+    int p2p_parity = 0;        // inbox half of the next exchange: flips with every exchange, whatever the sequence number does
+    int p2p_max_spin = 1 << 26;  // polls of a word before an exchange gives up (PVAE_P2P_SPIN_LOG2; ~a minute at the default)
     int* p2p_status = nullptr;
     bool p2p = false;
     // staged API: rows whose first-layer partial sums the last pvae_stage_c_next left in encpart (empty = none)
@@ -446,8 +448,10 @@ int shard_allreduce(pvae_engine* e, int which, int rows = 32) {
             peers.inbox[r] = r == e->cfg.rank ? e->p2p_inbox : reinterpret_cast<unsigned long long*>(e->p2p_peer[r]);
         ++e->p2p_seq;
         if (e->p2p_seq == 0) ++e->p2p_seq;  // 0 is what an untouched inbox holds
+        const int parity = e->p2p_parity;
+        e->p2p_parity ^= 1;
         hipLaunchKernelGGL(pvk_p2p_allreduce, dim3(std::min<size_t>(16, (n + 1023) / 1024)), dim3(256), 0, e->stream, buf, (int)n, peers,
-                           e->cfg.rank, e->cfg.world, e->p2p_seq, e->p2p_words, e->p2p_status);
+                           e->cfg.rank, e->cfg.world, e->p2p_seq, parity, e->p2p_words, e->p2p_status, e->p2p_max_spin);
         return launch_check(e, "p2p_allreduce");
     }
     const int rc = rccl()->AllReduce(buf, buf, n, 7 /* ncclFloat32 */, 0 /* ncclSum */, e->comm, e->stream);
@@ -2108,6 +2112,11 @@ int pvae_p2p_prepare(pvae_engine* e, char* handle64) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
     if (e->cfg.world < 1 || e->cfg.world > PV_P2P_MAX_WORLD) return set_err(e, -2, "one-shot exchange: world %d (at most %d)", e->cfg.world, PV_P2P_MAX_WORLD);
     HIPCHK(hipSetDevice(e->dev));
+    if (const char* sp = getenv("PVAE_P2P_SPIN_LOG2")) {  // how long an exchange waits for a peer's words before it gives up
+        const int lg = atoi(sp);
+        if (lg < 4 || lg > 30) return set_err(e, -2, "PVAE_P2P_SPIN_LOG2 = %s (4 .. 30)", sp);
+        e->p2p_max_spin = 1 << lg;
+    }
     if (!e->p2p_inbox) {
         e->p2p_words = (int64_t)32 * e->T * e->Wp + 32;  // the largest exchange: dg of a pass + the loss sums
         const size_t bytes = (size_t)2 * e->cfg.world * e->p2p_words * sizeof(unsigned long long);

@@ -2160,8 +2160,11 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
 #define PV_P2P_MAX_WORLD 16
 struct PvPeers { unsigned long long* inbox[PV_P2P_MAX_WORLD]; };
 __global__ __launch_bounds__(256) void pvk_p2p_allreduce(float* __restrict__ buf, int n, PvPeers peers, int rank, int world,
-                                                         unsigned seq, int64_t words, int* __restrict__ status) {
-    const int64_t slot = ((int64_t)(seq & 1) * world) * words;
+                                                         unsigned seq, int parity, int64_t words, int* __restrict__ status,
+                                                         int max_spin) {
+    // parity: the inbox half of this exchange; it flips with EVERY exchange (the host keeps it apart from the sequence number,
+    // which skips 0 when it wraps: derived from seq & 1, the exchanges 0xFFFFFFFF and 1 would share a half)
+    const int64_t slot = ((int64_t)parity * world) * words;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     for (int i = tid; i < n; i += nth) {
         const unsigned long long word = ((unsigned long long)seq << 32) | __float_as_uint(buf[i]);
@@ -2175,7 +2178,7 @@ __global__ __launch_bounds__(256) void pvk_p2p_allreduce(float* __restrict__ buf
             const unsigned long long* src = peers.inbox[rank] + slot + (int64_t)r * words + i;
             unsigned long long w = 0;
             ok = false;
-            for (int spin = 0; spin < (1 << 22); ++spin) {
+            for (int spin = 0; spin < max_spin; ++spin) {
                 w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if ((unsigned)(w >> 32) == seq) { ok = true; break; }
                 __builtin_amdgcn_s_sleep(2);

@@ -209,6 +209,21 @@ class ShardedEngine:
         self._p2p = True
         return True
 
+    def check_exchange(self):
+        """One-shot exchange only: an exchange whose wait for a peer's words ran out fills its buffer with NaN and raises a
+        status word on THAT rank (the late peer itself still receives valid sums).  Called once per epoch / encode; the ranks
+        agree on the outcome, and all of them raise: a run must not carry on -- and exit 0 -- with poisoned replicas."""
+        if not getattr(self, "_p2p", False):
+            return
+        try:
+            bad = bool(self.eng.p2p_gave_up())
+        except Exception:
+            bad = True
+        if not self._agree(not bad):
+            raise RuntimeError("one-shot exchange (PVAE_COMM=p2p): a rank gave up waiting for a peer's words "
+                               f"(this rank: {'gave up' if bad else 'ok'}); activations of that step were NaN-filled. "
+                               "Rerun with PVAE_COMM=rccl, or raise PVAE_P2P_SPIN_LOG2 if a rank is known to stall on the host")
+
     def comm_report(self):
         """For bench.py's --gpus N line: which exchange path runs and what RCCL itself says about the communicator."""
         out = {"path": "native" if self.native else ("host-staged" if (self.world > 1 or self.force_collectives) else "none"),
@@ -339,7 +354,9 @@ class ShardedEngine:
     def encode(self, rows, eps=None):
         rows = np.ascontiguousarray(rows, dtype=np.int32)
         if self.native:
-            return self.eng.encode(rows, eps)
+            out = self.eng.encode(rows, eps)
+            self.check_exchange()
+            return out
         outs = []
         for i0 in range(0, len(rows), 32):
             r = rows[i0:i0 + 32]
@@ -370,7 +387,9 @@ class ShardedEngine:
         perm = np.ascontiguousarray(perm, dtype=np.int32)
         val_rows = np.ascontiguousarray(val_rows, dtype=np.int32)
         if self.native and eps_fn is None:  # the C-side epoch loop, as on one GPU
-            return self.eng.train_epoch(perm, val_rows)
+            out = self.eng.train_epoch(perm, val_rows)
+            self.check_exchange()
+            return out
         tl, vl = [], []
         fuse = B <= 32
         for i0 in range(0, len(perm), B):
@@ -387,4 +406,12 @@ class ShardedEngine:
         self.eng.synchronize()
 
     def close(self):
+        if getattr(self, "_p2p", False) and self._dist.is_initialized():
+            # a peer may still be inside an exchange kernel that writes into this rank's inbox: everyone drains, then meets,
+            # before anyone unmaps or frees
+            try:
+                self.eng.synchronize()
+                self._dist.barrier(group=self.pg)
+            except Exception:
+                pass
         self.eng.close()

@@ -58,6 +58,35 @@ for B in (48, 160):
         assert big[0][0] == other[0], (B, big[0][0], other[0])
         for a, b in zip(big[0][1], other[1]):
             assert np.array_equal(a, b)
+# widths above 128 (BASELINE config 3 is width 512, SNP-sharded): the grouped decoder pass and the per-layer narrow kernels
+# behind the in-stream all-reduces -- exchange buffers of 32 x 256 / 32 x 512 (+ 32) floats -- with a one-rank RCCL communicator
+# and with the one-shot exchange (this rank as its only peer): epochs with two validation batches, single steps, encode
+for W2, D2 in ((256, 3), (512, 2)):
+    dc2, w2 = _problem(N, 2500, W2, D2, K, seed=37)
+    wide = []
+    for with_comm in (False, True, "p2p"):
+        e = engine.Engine(n_snps=2500, width=W2, depth=D2, latent_dim=K, batch_size=32, seed=5)
+        if with_comm == "p2p":
+            e.p2p_connect([e.p2p_prepare()])
+        elif with_comm:
+            e.comm_init(engine.Engine.comm_unique_id())
+        e.load_genotypes(prep.pack_dc(dc2))
+        e.set_weights([x.astype(np.float32) for x in w2])
+        res = [e.train_epoch(perm, val) for _ in range(2)]
+        res.append(e.train_step(perm[:32]))
+        res.append(e.train_step(perm[:11]))
+        res.append(e.eval_step(val[:32]))
+        mu, _, _ = e.encode(np.arange(N, dtype=np.int32))
+        if with_comm == "p2p":
+            assert not e.p2p_gave_up()
+        wide.append((res, e.get_weights(), mu))
+        e.close()
+    for other in wide[1:]:
+        assert wide[0][0] == other[0], (W2, wide[0][0], other[0])
+        assert all(np.isfinite(x) for r_ in other[0] for x in r_), other[0]
+        for a, b in zip(wide[0][1], other[1]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(wide[0][2], other[2])
 (ra, wa, ma), (rb, wb, mb) = outs
 assert ra == rb, (ra, rb)
 for a, b in zip(wa, wb):

@@ -216,6 +216,38 @@ def sharded_worker(rank, world, port, out_path, use_gpu, dims):
     dist.destroy_process_group()
 
 
+def p2p_giveup_worker(rank, world, port, out_path):
+    """One-shot exchange with a rank that does not show up for an exchange: rank 0 exchanges alone, its wait for rank 1's words
+    runs out (PVAE_P2P_SPIN_LOG2 keeps that short), and check_exchange -- what ShardedEngine.train_epoch / encode call -- must
+    raise on BOTH ranks (the ranks agree on the outcome)."""
+    sys.path.insert(0, ROOT)
+    dist = _init_pg(rank, world, port)
+    from popvae_amd.dist import ShardedEngine
+    from popvae_amd.engine import Engine
+    sh = ShardedEngine(n_snps=640, width=128, depth=2, latent_dim=2, batch_size=32, seed=3, device_id=0, engine_factory=Engine)
+    res = {"native": sh.native, "path": sh.comm_report()["path"], "raised": False, "clean_before": None}
+    try:
+        sh.check_exchange()
+        res["clean_before"] = True
+    except RuntimeError:
+        res["clean_before"] = False
+    # (the set-up's own test exchanges ran with the default, minute-long bound: two processes start their kernels milliseconds
+    # apart.)  pvae_p2p_prepare re-reads PVAE_P2P_SPIN_LOG2 on every call; the inbox is already there.
+    os.environ["PVAE_P2P_SPIN_LOG2"] = "10"
+    sh.eng.p2p_prepare()
+    if rank == 0:
+        sh.eng.comm_allreduce(0)   # nobody else takes part
+        res["nan"] = bool(np.isnan(sh.eng.exchange_read(0)).all())
+    try:
+        sh.check_exchange()
+    except RuntimeError as ex:
+        res["raised"] = "gave up" in str(ex)
+    np.save(out_path + f".{rank}.npy", np.array([res], dtype=object), allow_pickle=True)
+    sh.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def reference_run(dims):
     """The same sequence on the unsharded float64 oracle."""
     N, L, W, D, K = dims

@@ -180,3 +180,17 @@ def test_cli_parser_matches_reference_flags():
     for k, v in ref_defaults.items():
         assert getattr(a, k) == v, k
     assert a.init_weights is None   # the one flag the reference does not have
+
+
+def test_test_flag_resolves_its_input(tmp_path, monkeypatch):
+    """`popvae.py --test` (popvae.py:175-180) runs on data/pabu/pabu_test_genotypes.vcf relative to the working directory;
+    where that path does not exist (this repository keeps the fixture gzip-compressed under tests/golden/) it falls back to
+    that copy instead of failing."""
+    import os
+    from popvae_amd import cli
+    monkeypatch.chdir(tmp_path)
+    p = cli.test_infile()
+    assert p.endswith(os.path.join("tests", "golden", "pabu_test_genotypes.vcf.gz")) and os.path.exists(p)
+    os.makedirs(tmp_path / "data" / "pabu")
+    (tmp_path / "data" / "pabu" / "pabu_test_genotypes.vcf").write_text("##fileformat=VCFv4.2\n")
+    assert cli.test_infile() == os.path.join("data", "pabu", "pabu_test_genotypes.vcf")

@@ -179,14 +179,17 @@ def test_epoch_loop_equals_stepwise_at_full_size(L, W, D):
         assert np.abs(a - b).max() <= 1e-6, (i, np.abs(a - b).max())
 
 
-@pytest.mark.parametrize("L,D", [(1_000_000, 6), (4_000_031, 3)])
-def test_snp_shards_add_up_at_full_size(L, D):
+@pytest.mark.parametrize("L,W,D", [(1_000_000, 128, 6), (4_000_031, 128, 3),
+                                   # BASELINE config 3 (width 512, SNP-sharded) and a C5 cell at width 256: the grouped decoder
+                                   # pass (pvk_dec_grp) and the per-layer narrow kernels behind the staged calls
+                                   (500_000, 512, 6), (200_000, 256, 5)])
+def test_snp_shards_add_up_at_full_size(L, W, D):
     """Linearity of the two exchange points at 1M SNPs and at 4M + 31 SNPs (four times the headline shape, ragged last
     block: 64-bit tile offsets, 2 GB per wide tensor): two engines holding half of the SNP axis each, driven
     through the staged C ABI with the host adding their exchange buffers (pvae_exchange_copy), reproduce the unsharded loss and
-    the unsharded gradients (wide tensors: the matching slices)."""
+    the unsharded gradients (wide tensors: the matching slices) -- and, at widths 256 / 512, the float64 oracle's loss."""
     from popvae_amd.dist import shard_bounds, shard_packed
-    W, K, N, n = 128, 2, 40, 32
+    K, N, n = 2, 40, 32
     codes = _codes(N, L, seed=11)
     packed = _pack(codes)
     g = np.random.default_rng(2)
@@ -199,6 +202,10 @@ def test_snp_shards_add_up_at_full_size(L, D):
     loss, recon, kl = full.grad_step(rows, eps)
     gf = full.get_grads()
     full.close()
+    if W > 128:
+        c = O.forward([x.astype(np.float64) for x in w], codes[rows] * 0.5, eps.astype(np.float64), D, K)
+        assert abs(loss - c["loss"]) <= RTOL * abs(c["loss"]), (loss, c["loss"])
+        del c
     bounds = shard_bounds(L, 2)
     engs = []
     for r, (lo, hi) in enumerate(bounds):
@@ -233,3 +240,39 @@ def test_snp_shards_add_up_at_full_size(L, D):
         for i, (a, b) in enumerate(zip(gs, ref)):
             assert _relerr(a, b) <= 1e-5, (r, i, _relerr(a, b))
         e.close()
+
+
+def test_headline_shape_at_keras_default_lr():
+    """BASELINE's headline shape (1M SNPs, depth 6, width 128, batch 32) at the reference's own optimizer defaults
+    (`vae.compile(optimizer="adam")`, popvae.py:426: lr = 1e-3).  With a fan-in of 1M the first Adam step (every first-layer
+    weight moves by ~lr in the direction of its gradient's sign) throws the pre-activations out by hundreds, and the loss
+    explodes from 6.9e5 to ~3e10 within one step (measured: engine 2.94208e10 / oracle 2.94260e10 at step 1, 2.3508e10 /
+    2.3483e10 at step 2): a property of the model at this scale, which bench.py avoids by stepping at lr = 1e-4.  The engine
+    must do what the float32 oracle does at the same settings: the same losses while they are finite (step 0 to 1e-4; later
+    steps, where the float32 rounding of 128M updates of +-lr is amplified by the fan-in, to 5e-3), and non-finite at the same
+    step if at all."""
+    L, W, D, K, N, n = 1_000_000, 128, 6, 2, 40, 32
+    codes = _codes(N, L, seed=128)
+    w = O.init_weights(L, W, D, K, seed=7, dtype=np.float32)
+    e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=32, seed=0, lr=1e-3)
+    e.load_genotypes(_pack(codes))
+    e.set_weights(w)
+    opt = O.KerasAdam(w, lr=1e-3)
+    g = np.random.default_rng(5)
+    got, want = [], []
+    with np.errstate(all="ignore"):
+        for step in range(3):
+            rows = g.choice(N, n, replace=False).astype(np.int32)
+            eps = g.normal(size=(n, K)).astype(np.float32)
+            got.append(e.train_step(rows, eps))
+            lo, c = O.train_step(w, opt, (codes[rows] * np.float32(0.5)).astype(np.float32), eps, D, K)
+            want.append((float(lo), float(c["recon"].mean()), float(c["kl"].mean())))
+    e.close()
+    print("engine", got, "oracle", want)
+    for step, (a, b) in enumerate(zip(got, want)):
+        assert np.isfinite(a[0]) == np.isfinite(b[0]), (step, a, b)
+        if np.isfinite(b[0]):
+            tol = RTOL if step == 0 else 5e-3
+            assert abs(a[0] - b[0]) <= tol * abs(b[0]), (step, a, b)
+            assert abs(a[1] - b[1]) <= tol * abs(b[1]), (step, a, b)
+    assert want[1][0] > 1e3 * want[0][0]  # the blow-up itself: what makes lr = 1e-3 unusable at this fan-in

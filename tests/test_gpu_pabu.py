@@ -76,6 +76,21 @@ def test_reference_test_run_on_pabu(tmp_path, monkeypatch, capsys):
     assert ((proj > 0) == (pop == "E")).mean() >= 0.9
 
 
+def test_test_flag_runs_in_this_tree(tmp_path):
+    """`python popvae.py --test` itself (popvae.py:175-180), from a working directory that holds no data/pabu/: the flag spawns
+    the run on the repository's copy of the fixture and leaves out/pabu_test_* behind, as README.md:24-27 describes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    p = subprocess.run([sys.executable, os.path.join(root, "popvae.py"), "--test"], cwd=tmp_path, capture_output=True, text=True,
+                       timeout=280)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    assert "running on 3887 SNPs" in p.stdout
+    lat = open(tmp_path / "out" / "pabu_test_latent_coords.txt").read().splitlines()
+    assert lat[0].split("\t") == ["mean1", "mean2", "sd1", "sd2", "sampleID"] and len(lat) == 1 + GOLD["n_samples"]
+    assert os.path.getsize(tmp_path / "out" / "pabu_test_history.txt") > 0
+
+
 def test_cache_and_weight_files_through_the_cli(tmp_path, monkeypatch, capsys):
     """--save_allele_counts / .popvae.hdf5 input (popvae.py:205-209, 241-248) and --save_weights (popvae.py:429-435,
     525-526) through the CLI: the cache written next to the input file reproduces the run that wrote it (same SNPs, same

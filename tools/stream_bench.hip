@@ -127,6 +127,32 @@ __global__ __launch_bounds__(256) void k_read(const f32x4* a, size_t n4, float* 
     if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) out[0] = 1.f;
 }
 
+// D: plain copy (1 read stream + 1 write stream), the guide's reference point (float4 copy: 6.29 TB/s measured there)
+template <int NT>
+__global__ __launch_bounds__(256) void k_copy(const f32x4* a, f32x4* a2, size_t n4) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    for (; i < n4; i += st) {
+        const f32x4 x = NT ? __builtin_nontemporal_load(a + i) : a[i];
+        if (NT) __builtin_nontemporal_store(x, a2 + i);
+        else a2[i] = x;
+    }
+}
+// D2: copy with 4 independent float4 per lane in flight (grid-stride over 4-wide groups)
+template <int NT>
+__global__ __launch_bounds__(256) void k_copy4(const f32x4* a, f32x4* a2, size_t n4) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    for (; i + 3 * st < n4; i += 4 * st) {
+        f32x4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = NT ? __builtin_nontemporal_load(a + i + u * st) : a[i + u * st];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (NT) __builtin_nontemporal_store(x[u], a2 + i + u * st);
+            else a2[i + u * st] = x[u];
+        }
+    }
+}
+
 template <typename F>
 float timeit(F f, int reps = 10) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -171,6 +197,13 @@ int main() {
         vs.push_back({"oop chunk16 nt round-robin g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk_oop<16, 1>), dim3(g), dim3(256), 0, 0, A, B, C, A2, B2, C2, n4 / (16 * 64)); }, 3, {}});
         vs.push_back({"oop chunk4 nt round-robin g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk_oop<4, 1>), dim3(g), dim3(256), 0, 0, A, B, C, A2, B2, C2, n4 / (4 * 64)); }, 3, {}});
     }
+    // plain copies of the 1.5 GB interleaved buffer into the other one: 3 GB moved, the traffic of one wide training kernel at C4
+    for (int g : {512, 1024, 2048, 4096}) {
+        vs.push_back({"copy 1.5GB->1.5GB g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_copy<0>), dim3(g), dim3(256), 0, 0, IL, IL2, 3 * n4); }, -1, {}});
+        vs.push_back({"copy 1.5GB->1.5GB nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_copy<1>), dim3(g), dim3(256), 0, 0, IL, IL2, 3 * n4); }, -1, {}});
+        vs.push_back({"copy x4 1.5GB->1.5GB nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_copy4<1>), dim3(g), dim3(256), 0, 0, IL, IL2, 3 * n4); }, -1, {}});
+    }
+    vs.push_back({"hipMemcpyAsync D2D 1.5GB", [=] { hipMemcpyAsync(il2, il, 3 * n * 4, hipMemcpyDeviceToDevice, 0); }, -1, {}});
     for (int g : {512, 1024}) {
         vs.push_back({"read-only g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_read<0>), dim3(g), dim3(256), 0, 0, A, n4, o); }, 0, {}});
         vs.push_back({"read-only nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_read<1>), dim3(g), dim3(256), 0, 0, A, n4, o); }, 0, {}});
@@ -179,7 +212,7 @@ int main() {
         for (auto& v : vs) v.ms.push_back(timeit(v.f, 3));
     for (auto& v : vs) {
         std::sort(v.ms.begin(), v.ms.end());
-        const double bytes = v.narr ? v.narr * 2.0 * n * 4 : 1.0 * n * 4;
+        const double bytes = v.narr < 0 ? 6.0 * n * 4 : v.narr ? v.narr * 2.0 * n * 4 : 1.0 * n * 4;
         printf("%-40s median %7.1f us (%5.0f GB/s)  min %7.1f us (%5.0f GB/s)  max %7.1f\n", v.name.c_str(), v.ms[3] * 1e3,
                bytes / (v.ms[3] * 1e-3) / 1e9, v.ms[0] * 1e3, bytes / (v.ms[0] * 1e-3) / 1e9, v.ms[6] * 1e3);
     }
