@@ -530,8 +530,8 @@ int build_bwd_ops(pvae_engine* e, bool grad, PvBwdOp** out) {
         }
         o.dpre = e->dpre_bufs[nd++];
         if (e->fused_narrow && !d.wf) {
-            if (hipMalloc(&d.wf, (size_t)d.kin * d.nout * sizeof(float)) != hipSuccess) d.wf = nullptr;
-            if (hipMalloc(&d.wb, (size_t)d.kin * d.nout * sizeof(float)) != hipSuccess) d.wb = nullptr;
+            if (hipMalloc(&d.wf, pvn_wf_floats(d.kin, d.nout) * sizeof(float)) != hipSuccess) d.wf = nullptr;
+            if (hipMalloc(&d.wb, pvn_wb_floats(d.kin, d.nout) * sizeof(float)) != hipSuccess) d.wb = nullptr;
             if (!d.wf || !d.wb) alloc_failed = true;
         }
         o.Wf = d.wf; o.Wb = d.wb;
@@ -593,8 +593,8 @@ int ensure_narrow_packed(pvae_engine* e) {
 int narrow_fused_fwd(pvae_engine* e, bool encoder_only, bool decoder_only = false, int tiles = 1) {
     int rc0;
     if ((rc0 = ensure_narrow_packed(e))) return rc0;
-    const int nops = encoder_only ? e->n_enc_ops : e->n_fwd_ops, nworkers = PVN_WORKERS * tiles;
-    hipLaunchKernelGGL(pvk_narrow_fwd, dim3(e->narrow_warm ? 8 * (nops + 1) : nworkers), dim3(PVN_THREADS), pvn_lds_fwd(), e->stream,
+    const int nops = encoder_only ? e->n_enc_ops : e->n_fwd_ops, nworkers = PVQ_WORKERS_PER_TILE * tiles;
+    hipLaunchKernelGGL(pvk_narrow_fwd, dim3(e->narrow_warm ? nworkers + 8 * nops : nworkers), dim3(PVQ_THREADS), pvn_lds_fwd(), e->stream,
                        e->d_fwd_ops, decoder_only ? e->n_enc_ops : 0, nops, e->P, e->eps, e->K, e->Kz, e->z, e->kl, nworkers);
     return launch_check(e, "narrow_fwd");
 }
@@ -765,10 +765,10 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
         const bool ride = mode == 0;
         {
         Timer t(e, C_NARROW_BWD);
-        const dim3 chain_grid(mode == 1 ? 1 : e->narrow_warm ? 8 * (e->n_bwd_ops + 1) : PVN_WORKERS);
+        const dim3 chain_grid(mode == 1 ? 1 : e->narrow_warm ? PVQ_WORKERS_PER_TILE + 8 * e->n_bwd_ops : PVQ_WORKERS_PER_TILE);
 #define PV_NARROW_BWD(MD)                                                                                                      \
-    hipLaunchKernelGGL(pvk_narrow_bwd<MD>, chain_grid, dim3(PVN_THREADS), pvn_lds_bwd(), e->stream, table, e->n_bwd_ops, e->xch1, \
-                       e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st, e->adam, d_out3, mode == 1 ? 0 : 1, (int)PVN_WORKERS)
+    hipLaunchKernelGGL(pvk_narrow_bwd<MD>, chain_grid, dim3(PVQ_THREADS), pvn_lds_bwd(), e->stream, table, e->n_bwd_ops, e->xch1, \
+                       e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st, e->adam, d_out3, mode == 1 ? 0 : 1, (int)PVQ_WORKERS_PER_TILE)
         if (km == PV_MODE_GRAD) PV_NARROW_BWD(PV_MODE_GRAD);
         else if (km == PV_MODE_TRAIN_ACC) PV_NARROW_BWD(PV_MODE_TRAIN_ACC);
         else PV_NARROW_BWD(PV_MODE_TRAIN);
@@ -973,10 +973,10 @@ int multi_tile_launches(pvae_engine* e, int row_offset, float* d_out3, int mode)
     {
         Timer t(e, C_NARROW_BWD);
         if ((rc = ensure_narrow_packed(e))) return rc;
-        const dim3 chain_grid(e->narrow_warm ? 8 * (e->n_bwd_ops + 1) : PVN_WORKERS * T);
+        const dim3 chain_grid(e->narrow_warm ? PVQ_WORKERS_PER_TILE * T + 8 * e->n_bwd_ops : PVQ_WORKERS_PER_TILE * T);
 #define PV_NARROW_BWD_T(MD)                                                                                                        \
-    hipLaunchKernelGGL(pvk_narrow_bwd<MD>, chain_grid, dim3(PVN_THREADS), pvn_lds_bwd(), e->stream, table, e->n_bwd_ops, e->xch1,   \
-                       e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st, e->adam, d_out3, 1, (int)PVN_WORKERS * T)
+    hipLaunchKernelGGL(pvk_narrow_bwd<MD>, chain_grid, dim3(PVQ_THREADS), pvn_lds_bwd(), e->stream, table, e->n_bwd_ops, e->xch1,   \
+                       e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st, e->adam, d_out3, 1, (int)PVQ_WORKERS_PER_TILE * T)
         if (km == PV_MODE_GRAD) {
             PV_NARROW_BWD_T(PV_MODE_GRAD);
             hipLaunchKernelGGL(pvk_narrow_adam<PV_MODE_GRAD>, dim3(16, e->n_bwd_ops), dim3(64), 0, e->stream, table, e->st, e->adam, T);
@@ -1086,9 +1086,9 @@ int multi_tile_eval_launches(pvae_engine* e, int row_offset, int nrows, int n_ba
         if ((rc = launch_check(e, "dec_eval"))) return rc;
     }
     if ((rc = shard_allreduce(e, 1, R))) return rc;
-    hipLaunchKernelGGL(pvk_narrow_bwd<PV_MODE_TRAIN>, dim3(1), dim3(PVN_THREADS), pvn_lds_bwd(), e->stream, (const PvBwdOp*)e->d_bwd_ops,
+    hipLaunchKernelGGL(pvk_narrow_bwd<PV_MODE_TRAIN>, dim3(1), dim3(PVQ_THREADS), pvn_lds_bwd(), e->stream, (const PvBwdOp*)e->d_bwd_ops,
                        e->n_bwd_ops, e->xch1, e->Wp, e->kl, e->eps, e->headout, e->Kh, e->K, e->st, e->adam, d_out3, 0,
-                       (int)PVN_WORKERS * T);
+                       (int)PVQ_WORKERS_PER_TILE * T);
     return launch_check(e, "loss");
 }
 int multi_tile_eval(pvae_engine* e, int row_offset, int nrows, int n_batch, float* d_out3, int nbatches = 0) {

@@ -1,67 +1,73 @@
-// pvae_narrow.h -- the narrow part of the VAE (everything between the two wide layers) as ONE workgroup.
+// pvae_narrow.h -- the narrow part of the VAE (everything between the two wide layers) as chains of 4-row workers.
 //
 // For widths up to 128 the hidden layers (popvae.py:395-398, 404-406), the reparameterisation (:384-389),
 // the KL term (:419-421) and their backward + Adam are a few hundred KFLOP on 64 KB matrices: launch- and
-// latency-bound, not throughput-bound.  Two kernels (forward, backward) walk an op table with the batch
-// activations resident in LDS, instead of ~26 small launches per step.  One workgroup of 8 waves:
-//   * weights go straight from global memory (L2-resident after the warm-up role) into MFMA B operands;
-//     the next layer's operands are loaded while the current layer computes;
-//   * A operands (activations / dpre) come from LDS with ds_read_b128, row stride 132 floats;
-//   * every wave owns 16 output columns of a layer (v_mfma_f32_16x16x4_f32): no partial sums, one barrier per layer,
-//     a fixed summation order (deterministic).
+// latency-bound, not throughput-bound.  Two kernels (forward, backward) walk an op table with the activations
+// resident in LDS, instead of ~26 small launches per step.
+//
+// Round 3: the batch's rows never meet inside the chain, so it is cut into workers of FOUR rows -- eight workgroups for a
+// 32-row batch, one per die -- and a layer is done with v_mfma_f32_4x4x1_16B_f32 in its A-broadcast form (cbsz = 4):
+// D[4 rows][64 columns] += A[4 rows][k] * B[k][64 columns], one contraction step per instruction, 8 cycles each.  With 16-row
+// tiles (v_mfma_f32_16x16x4_f32, two workers, rounds 1-2) a layer was 2048 cycles of each CU's matrix pipe plus ~1.2 us of
+// barrier / epilogue among eight waves; with four rows it is 1024 cycles (tools/mfma4_probe.hip: 1113 measured) on TWO
+// waves -- wave h owns output columns [64 h, 64 h + 64) -- that meet at one cheap two-wave barrier per layer:
+//   * weights go straight from global memory (L2-resident after the warm-up role) into the B operands: lane l of wave h
+//     holds column 64 h + l of the layer's kernel, all kin rows of it (<= 128 registers); the next layer's are loaded
+//     while the current layer computes (another 128 registers: one wave per SIMD, 512-register budget);
+//   * activations live in LDS as [k][4 rows]: the A operand of 16 contraction steps is ONE conflict-free ds_read_b32 per lane
+//     (lane 4 b + i holds row i of step 16 j + b; instruction b of the group broadcasts block b: abid = b), and a lane's four
+//     results -- rows 0..3 of its column -- go back as one ds_write_b128;
+//   * a fixed summation order (deterministic), the same on every rank of an SNP-sharded model.
 // Wider layers (width 256/512) use the per-layer kernels in pvae_kernels.h, which spread a layer over CUs.
 #pragma once
 #include "pvae_kernels.h"
 
-#define PVN_LD 132
-// The batch's 32 rows are independent through the whole chain, so the chain runs as PVN_WORKERS workgroups on as many
-// CUs, each with PVN_NT 16-row tiles: half the MFMAs per layer on each CU's matrix pipe, no communication at all.
-#define PVN_NT 1
-#define PVN_WORKERS (2 / PVN_NT)
-#define PVN_ROWS (16 * PVN_NT)
-#define PVN_THREADS 512
+#define PVQ_ROWS 4                 // batch rows per worker
+#define PVQ_THREADS 128            // two waves: wave h owns output columns [64 h, 64 h + 64)
+#define PVQ_WORKERS_PER_TILE 8     // workers per 32-row tile of a device pass
+#define PVQ_LDA (128 * PVQ_ROWS)   // floats of one activation buffer in LDS: [k < 128][row < 4]
 
 enum { PVN_DENSE = 0, PVN_BIAS_ACT = 1, PVN_REPARAM = 2, PVN_FIRST_BIAS = 3 };
 
 struct PvFwdOp {
     const float* W;  // operand-order copy of the kernel (pvn_wf_index below); the Keras-layout original is PvBwdOp::W
     const float* b;  // [nout]
-    float* out;      // global copy of the layer output [32][nout] (needed by the backward pass)
+    float* out;      // global copy of the layer output [rows][nout] (needed by the backward pass)
     int kin, nout, act, kind;
 };
 
 struct PvBwdOp {
     // -- read by the chain kernel for every op (the first PVN_BWD_LEAN dwords) --
     float* Wb;           // operand-order copy of the kernel for dIn = dpre * W^T (pvn_wb_index below)
-    const float* Y;      // layer output [32][nout]
-    float* dpre;         // dLoss/d(pre-activation) [32][nout]: written by the chain kernel, read by pvk_narrow_adam
+    const float* Y;      // layer output [rows][nout]
+    float* dpre;         // dLoss/d(pre-activation) [rows][nout]: written by the chain kernel, read by pvk_narrow_adam
     int kin, nout, act, kind;
     // -- pvk_narrow_adam / FIRST_BIAS only --
     float *mW, *vW;      // MODE_GRAD: mW = gradient dump, vW unused
     float *B, *mB, *vB;
-    const float* in;     // layer input  [32][kin]
+    const float* in;     // layer input  [rows][kin]
     const float *gW, *gB;  // MODE_TRAIN_ACC: gradients accumulated over the earlier tiles of the batch
     float* W;            // [kin][nout] row-major (padded to multiples of 32): the Keras-layout kernel
     float* Wf;           // operand-order copy for the forward chain
 };
 #define PVN_BWD_LEAN 10
 
-// Operand-order copies of a narrow kernel W[kin][nout].  The chain kernels feed v_mfma_f32_16x16x4_f32 straight from
-// global memory: wave w owns 16 output columns, lane (n = lane & 15, q = lane >> 4) the contraction quarter q, and a
-// "chunk" c is the 4 consecutive contraction steps 4c .. 4c + 3.  Read from the Keras layout, one wave instruction
-// touches 4 (forward) or 64 (backward) different cache lines, and the CU's address unit -- not the matrix pipe --
-// bounds a layer.  In these copies a wave's chunk is 1 KB contiguous (lane-major, 16 B per lane):
-//   forward   Wf[((w * kin/16 + c) * 64 + lane) * 4 + e]  = W[q * kin/4 + 4c + e][16w + n]
-//   backward  Wb[((w * nout/16 + c) * 64 + lane) * 4 + e] = W[16w + n][q * nout/4 + 4c + e]
-// pvk_narrow_adam keeps them in step with W; pvk_narrow_pack rebuilds them after any other write to W.
+// Operand-order copies of a narrow kernel W[kin][nout].  The chain kernels feed the matrix instruction straight from
+// global memory: lane l of wave h holds ONE output column, 64 h + l, for every contraction step, and a "chunk" c is the 4
+// consecutive contraction steps 4c .. 4c + 3.  In these copies a wave's chunk is 1 KB contiguous (lane-major, 16 B per lane):
+//   forward   (out = in * W,     column = output unit n)  Wf[((h * kin/4  + c) * 64 + l) * 4 + e] = W[4c + e][64 h + l]
+//   backward  (dIn = dpre * W^T, column = input unit k)   Wb[((h * nout/4 + c) * 64 + l) * 4 + e] = W[64 h + l][4c + e]
+// Columns beyond the layer (64 h + l >= nout resp. kin) hold zeros.  pvk_narrow_adam keeps the copies in step with W;
+// pvk_narrow_pack rebuilds them after any other write to W.
 __host__ __device__ inline int pvn_wf_index(int k, int col, int kin) {
-    const int ks = kin >> 2, q = k / ks, rem = k - q * ks;
-    return ((((col >> 4) * (ks >> 2) + (rem >> 2)) * 64) + q * 16 + (col & 15)) * 4 + (rem & 3);
+    return ((((col >> 6) * (kin >> 2) + (k >> 2)) * 64) + (col & 63)) * 4 + (k & 3);
 }
 __host__ __device__ inline int pvn_wb_index(int k, int col, int nout) {
-    const int ks = nout >> 2, q = col / ks, rem = col - q * ks;
-    return ((((k >> 4) * (ks >> 2) + (rem >> 2)) * 64) + q * 16 + (k & 15)) * 4 + (rem & 3);
+    return ((((k >> 6) * (nout >> 2) + (col >> 2)) * 64) + (k & 63)) * 4 + (col & 3);
 }
+// floats of the two copies
+__host__ __device__ inline size_t pvn_wf_floats(int kin, int nout) { return (size_t)((nout + 63) / 64) * 64 * kin; }
+__host__ __device__ inline size_t pvn_wb_floats(int kin, int nout) { return (size_t)((kin + 63) / 64) * 64 * nout; }
 
 // Pointers that come out of an op descriptor have lost their address space: the compiler would use FLAT loads and
 // stores for them, which count on the LDS counter as well -- every wait for an LDS read would then also wait for the
@@ -73,12 +79,8 @@ __device__ __forceinline__ pvn_gf* pvn_g(float* p) { return (pvn_gf*)p; }
 __device__ __forceinline__ const pvn_gf4* pvn_g4(const float* p) { return (const pvn_gf4*)p; }
 
 #define PVN_MAXOPS 64
-__host__ __device__ inline size_t pvn_lds_fwd() {
-    return (size_t)(2 * 32 * PVN_LD) * 4 + PVN_MAXOPS * sizeof(PvFwdOp);
-}
-__host__ __device__ inline size_t pvn_lds_bwd() {
-    return (size_t)(2 * 32 * PVN_LD) * 4 + PVN_MAXOPS * sizeof(PvBwdOp);
-}
+__host__ __device__ inline size_t pvn_lds_fwd() { return (size_t)(2 * PVQ_LDA) * 4 + PVN_MAXOPS * sizeof(PvFwdOp); }
+__host__ __device__ inline size_t pvn_lds_bwd() { return (size_t)(2 * PVQ_LDA) * 4 + PVN_MAXOPS * sizeof(PvBwdOp); }
 
 // The op table is cold in every launch (each step streams gigabytes through the caches in between), and a
 // scalar load that misses to HBM costs ~1-2 us per layer.  So the whole table is copied into LDS with one
@@ -86,17 +88,17 @@ __host__ __device__ inline size_t pvn_lds_bwd() {
 template <typename T>
 __device__ __forceinline__ void pvn_stage_ops(const T* __restrict__ ops, int nops, int* ops_s, int tid) {
     const int n = nops * (int)(sizeof(T) / 4);
-    for (int e = tid; e < n; e += PVN_THREADS) ops_s[e] = reinterpret_cast<const int*>(ops)[e];
+    for (int e = tid; e < n; e += PVQ_THREADS) ops_s[e] = reinterpret_cast<const int*>(ops)[e];
 }
-// L2 warm-up role.  The narrow kernels are launched with 8 * (nops + 1) workgroups; workgroup 0 does the work.
-// Workgroups 8, 16, 24, ... are (by the dispatcher's round-robin placement) on the same XCD as workgroup 0 and
-// share its L2: workgroup 8*(p+1) pulls op p's weight matrix through that L2 and exits, so that the worker's
-// operand loads -- 64 KB per layer, cold after the gigabytes the wide kernels streamed -- hit L2 instead of
-// paying several HBM round trips per layer.  Purely a hint: placement affects speed only, never results.
+// L2 warm-up role.  The chain kernels are launched with nworkers + 8 * nops workgroups; the first nworkers (a multiple of
+// 8: one per die and 32-row tile) do the work.  Workgroup nworkers + 8 p + x lands (by the dispatcher's round-robin
+// placement) on die x: it pulls op p's weight matrix through that die's L2 and exits, so that the workers' operand
+// loads -- 64 KB per layer, cold after the gigabytes the wide kernels streamed -- hit L2 instead of paying several HBM
+// round trips per layer.  Purely a hint: placement affects speed only, never results.
 __device__ __forceinline__ void pvn_warm_l2(const float* p, int nfloats, int tid) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const f32x4* q = reinterpret_cast<const f32x4*>(p);
-    for (int e = tid; e < (nfloats >> 2); e += PVN_THREADS) acc += q[e];
+    for (int e = tid; e < (nfloats >> 2); e += PVQ_THREADS) acc += q[e];
     asm volatile("" ::"v"(acc));
 }
 
@@ -130,215 +132,200 @@ __device__ unsigned long long pvn_trace_buf[2048];
 #define PVN_T(slot) do {} while (0)
 #endif
 
-// 32 MFMA B operands of a lane as two SSA vectors (a float[32] passed by reference ends up in scratch)
-struct PvW32 {
-    f32x16 lo, hi;
+// 128 B operands of a lane (its column of a layer's kernel) as SSA vectors (a float[128] passed by reference ends up in scratch)
+struct PvW128 {
+    f32x16 v[8];
 };
-#define PVN_W(w, s) ((s) < 16 ? (w).lo[(s) & 15] : (w).hi[(s) & 15])
-#define PVN_WSET(w, s, val)                     \
-    do {                                        \
-        if ((s) < 16) (w).lo[(s) & 15] = (val); \
-        else (w).hi[(s) & 15] = (val);          \
-    } while (0)
+#define PVQ_W(w, k) ((w).v[(k) >> 4][(k) & 15])
 
-// ---------------------------------------------------------------------------------------------
-// One dense layer on one CU is bound by the fp32 matrix pipe: 32 x 128 x 128 MACs at 128 MAC/cycle/CU = 4096
-// cycles (1.7 us) -- so everything else (operand loads, reductions, barriers) has to stay off the critical path:
-//   * the OUTPUT columns are split over the 8 waves (16 columns each, v_mfma_f32_16x16x4_f32, two 16-row tiles):
-//     no cross-wave reduction, no partial sums through LDS, ONE barrier per layer;
-//   * the contraction index is permuted so that lane group q = lane >> 4 owns the contiguous quarter
-//     [q * KS, (q + 1) * KS) of it (KS = kin / 4): the A operands of a layer are 2 x KS/4 ds_read_b128 per lane from
-//     the LDS-resident activations (row stride 132 floats: 16 consecutive lanes cover all 64 banks);
-//   * the next layer's B operands (<= 32 VGPRs per lane) are loaded from global memory (L2-resident after the
-//     warm-up role below) while the current layer's MFMAs run; activations ping-pong between two LDS buffers.
-// Accumulator layout of 16x16x4: lane (n = lane & 15, q = lane >> 4) holds rows 4q + r, r < 4, of column n.
-// ---------------------------------------------------------------------------------------------
-// The layer's MFMAs with the NEXT op's 32 B operands loaded in between (8 chunks of 4 spread over the KS/4
-// iterations): issued in one burst ahead of the MFMAs, 8 waves x 32 loads queue up in the CU's one address unit for
-// ~1 us before the first MFMA can issue.  The chunk index is clamped to the next op's own operand count (re-loading
-// its last chunk) so that no load sits under a condition.  nbase / nch are wave-uniform (SGPRs): scalar address math.
-// chunk c of this wave's next B operands: 1 KB per wave instruction (c is clamped to the op's own chunk count, so that no
-// load sits under a condition; a wave with nothing to prefetch passes nch = 1 and any valid 1 KB)
-__device__ __forceinline__ void pvn_load_chunk(PvW32& wn, int c, const float* nbase, int nch, int lane) {
-    const f32x4 v = pvn_g4(nbase + 256 * min(c, nch - 1))[lane];
+// chunk c (contraction steps 4c .. 4c + 3) of this wave's next B operands: 1 KB per wave instruction.  c is clamped to the
+// op's own chunk count, so that no load sits under a condition (a wave with nothing to prefetch passes nch = 1 and any valid
+// 1 KB); nbase / nch are wave-uniform (SGPRs): scalar address math.
+template <int C>
+__device__ __forceinline__ void pvq_load_chunk(PvW128& wn, const float* nbase, int nch, int lane) {
+    const f32x4 v = pvn_g4(nbase + 256 * min(C, nch - 1))[lane];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) PVN_WSET(wn, 4 * c + e, v[e]);
+    for (int e = 0; e < 4; ++e) wn.v[C >> 2][(4 * C + e) & 15] = v[e];
 }
-template <int KS>
-__device__ __forceinline__ void pvn_mma(f32x4 (&acc)[2], const float* a0, const PvW32& w, PvW32& wn, const float* nbase,
-                                        int nch, int lane) {
-    // acc[0], acc[1]: the two row tiles (PVN_NT == 2), or the even-k / odd-k partial sums of the one tile (PVN_NT == 1:
-    // two chains keep dependent MFMAs 2 apart; the caller adds them)
-    constexpr int NI = KS / 4, LI = NI - NI / 4;  // the last quarter stays free of loads: the drain follows right behind
-    f32x4 x0[NI], x1[PVN_NT == 2 ? NI : 1];
-#pragma unroll
-    for (int q = 0; q < NI; ++q) {
-        x0[q] = *reinterpret_cast<const f32x4*>(a0 + 4 * q);
-        if (PVN_NT == 2) x1[q] = *reinterpret_cast<const f32x4*>(a0 + 16 * PVN_LD + 4 * q);
+template <int C0, int C1>
+__device__ __forceinline__ void pvq_load_chunks(PvW128& wn, const float* nbase, int nch, int lane) {
+    if constexpr (C0 < C1) {
+        pvq_load_chunk<C0>(wn, nbase, nch, lane);
+        pvq_load_chunks<C0 + 1, C1>(wn, nbase, nch, lane);
     }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < NI; ++q) {
-        if (q < LI) {
-#pragma unroll
-            for (int c = q * 8 / LI; c < (q + 1) * 8 / LI; ++c) pvn_load_chunk(wn, c, nbase, nch, lane);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (PVN_NT == 2) {
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[q][e], PVN_W(w, 4 * q + e), acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[PVN_NT == 2 ? q : 0][e], PVN_W(w, 4 * q + e), acc[1], 0, 0, 0);
-            } else {
-                acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[q][e], PVN_W(w, 4 * q + e), acc[e & 1], 0, 0, 0);
-            }
-        }
+}
+// the 32 chunks without a layer to hide behind (first op, ops without matrix instructions)
+__device__ __forceinline__ void pvq_prefetch_plain(PvW128& wn, const float* nbase, int nch, int lane) {
+    pvq_load_chunks<0, 32>(wn, nbase, nch, lane);
+}
+// 16 contraction steps: instruction b takes the A operand of block b (lanes 4b .. 4b + 3: rows 0..3 of step 16 j + b) for all
+// 64 columns (cbsz = 4, abid = b); four accumulators in rotation keep dependent instructions four apart
+template <int J, int B>
+__device__ __forceinline__ void pvq_mm16(f32x4 (&acc)[4], float a, const PvW128& w) {
+    if constexpr (B < 16) {
+        acc[B & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, PVQ_W(w, 16 * J + B), acc[B & 3], 4, B, 0);
+        pvq_mm16<J, B + 1>(acc, a, w);
+    }
+}
+template <int KC16, int J>
+__device__ __forceinline__ void pvq_mma_groups(f32x4 (&acc)[4], const float (&a)[KC16], const PvW128& w, PvW128& wn,
+                                               const float* nbase, int nch, int lane) {
+    if constexpr (J < KC16) {
+        // this group's share of the next op's 32 chunks, issued ahead of its 16 matrix instructions: in one burst ahead of
+        // the whole layer the 64 loads of the two waves would queue at the CU's one address unit before the first instruction
+        pvq_load_chunks<J * 32 / KC16, (J + 1) * 32 / KC16>(wn, nbase, nch, lane);
+        pvq_mm16<J, 0>(acc, a[J], w);
         __builtin_amdgcn_sched_barrier(0);
+        pvq_mma_groups<KC16, J + 1>(acc, a, w, wn, nbase, nch, lane);
     }
-    if (PVN_NT == 1) acc[0] += acc[1];
 }
-// the same 8 chunks without a layer to hide behind (first op, ops without MFMAs)
-__device__ __forceinline__ void pvn_prefetch_plain(PvW32& wn, const float* nbase, int nch, int lane) {
+// One layer's matrix instructions for this wave's 64 columns: a_lds = activation buffer + lane ([k][4 rows]: the operand of
+// steps 16 j .. 16 j + 15 is the word at 64 j + lane), KC16 = contraction length / 16.
+template <int KC16>
+__device__ __forceinline__ f32x4 pvq_mma(const float* a_lds, const PvW128& w, PvW128& wn, const float* nbase, int nch, int lane) {
+    float a[KC16];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) pvn_load_chunk(wn, c, nbase, nch, lane);
+    for (int j = 0; j < KC16; ++j) a[j] = a_lds[64 * j];
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+    pvq_mma_groups<KC16, 0>(acc, a, w, wn, nbase, nch, lane);
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 // Wait-count discipline.  gfx9 has ONE counter for vector loads and stores, and with both kinds outstanding the compiler
 // has to wait for everything at the first use of a loaded register; __syncthreads() adds a full drain per layer on top
 // (its workgroup fence covers global memory).  Either would put ~1 us of store-acknowledge / load latency between
-// two layers.  So per op: the next op's operands are loaded DURING this op's MFMAs, the counter is drained once right
-// AFTER the MFMAs (the loads have had the whole MFMA phase, the previous op's stores a whole op), only then does the
+// two layers.  So per op: the next op's operands are loaded DURING this op's matrix instructions, the counter is drained once
+// right AFTER them (the loads have had the whole phase, the previous op's stores a whole op), only then does the
 // epilogue issue this op's stores, and the barrier between ops orders LDS only.
 #define PVN_DRAIN_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70) /* vmcnt(0), expcnt / lgkmcnt untouched */
 __device__ __forceinline__ void pvn_lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-
 }
-#define PVN_SWITCH(ks, ...)                                      \
-    switch ((ks) >> 3) {                                         \
-        case 1: { constexpr int S_ = 8; __VA_ARGS__; } break;    \
-        case 2: { constexpr int S_ = 16; __VA_ARGS__; } break;   \
-        case 3: { constexpr int S_ = 24; __VA_ARGS__; } break;   \
-        default: { constexpr int S_ = 32; __VA_ARGS__; } break;  \
+// contraction lengths are multiples of 32 up to 128
+#define PVQ_SWITCH(kc, ...)                                       \
+    switch ((kc) >> 5) {                                          \
+        case 1: { constexpr int C_ = 2; __VA_ARGS__; } break;     \
+        case 2: { constexpr int C_ = 4; __VA_ARGS__; } break;     \
+        case 3: { constexpr int C_ = 6; __VA_ARGS__; } break;     \
+        default: { constexpr int C_ = 8; __VA_ARGS__; } break;    \
     }
 
 // ---------------------------------------------------------------------------------------------
 // forward.  ops[0] = BIAS_ACT (h1 = elu(P + b1)), hidden layers, heads, REPARAM (+KL), decoder layers; nops may
 // stop after REPARAM (encoder.predict); op0 > 0 starts behind REPARAM with z (decoder.predict).
+// Worker w = workgroup w < nworkers handles batch rows 4 w .. 4 w + 3 of the device pass.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __restrict__ ops, int op0, int nops,
+__global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_fwd(const PvFwdOp* __restrict__ ops, int op0, int nops,
                                                               const float* __restrict__ P,
                                                               const float* __restrict__ eps, int K, int Kz,
                                                               float* __restrict__ z_out, float* __restrict__ kl_out,
                                                               int nworkers) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* cur = smem;                   // [PVN_ROWS][PVN_LD] of the [32][PVN_LD] reserved
-    float* nxt = smem + 32 * PVN_LD;
-    int* ops_s = reinterpret_cast<int*>(smem + 2 * 32 * PVN_LD);
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, q = lane >> 4;
-    const int n0 = wave * 16;
-    const int rb = PVN_ROWS * (int)blockIdx.x;  // first batch row of this worker
-    // nworkers = 2 per 32-row tile of the device pass (1 tile, or up to 4 for a batch above 32 rows in one weight pass);
-    // at most 8, so that the workers are the first eight workgroups: one per die
+    float* cur = smem;                   // [k][PVQ_ROWS]
+    float* nxt = smem + PVQ_LDA;
+    int* ops_s = reinterpret_cast<int*>(smem + 2 * PVQ_LDA);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int n = wave * 64 + lane;             // this lane's output column
+    const int rb = PVQ_ROWS * (int)blockIdx.x;  // first batch row of this worker
     if ((int)blockIdx.x >= nworkers) {
-        // warm-up role: block 8 (p + 1) + w shares (by the dispatcher's round-robin placement) the XCD of worker w
-        const int p = (int)(blockIdx.x >> 3) - 1;
-        if (blockIdx.x >= 8 && (int)(blockIdx.x & 7) < nworkers && p >= 0 && p < nops) {
+        const int p = ((int)blockIdx.x - nworkers) >> 3;
+        if (p < nops) {
             const PvFwdOp op = ops[p];
-            if (op.kind == PVN_DENSE) pvn_warm_l2(op.W, op.kin * op.nout, tid);
+            if (op.kind == PVN_DENSE) pvn_warm_l2(op.W, (int)pvn_wf_floats(op.kin, op.nout), tid);
         }
         return;
     }
     pvn_stage_ops(ops, nops, ops_s, tid);
     __syncthreads();
 
-    PvW32 wnext;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) wnext.lo[s] = wnext.hi[s] = 0.f;
-    // where this lane's B operands of op `o` start (element s at src[s * stride], s < ks); a wave that has
-    // nothing to load for `o` gets a harmless address
+    // where this wave's B operands of op `o` start; a wave that has nothing to load for `o` gets a harmless address
     const float* nbase = P;
     int nch = 1;
     auto aim = [&](const PvFwdOp& o) {
         nbase = P; nch = 1;
-        if (o.kind != PVN_DENSE || n0 >= o.nout) return;
-        nch = o.kin >> 4;
+        if (o.kind != PVN_DENSE || wave * 64 >= o.nout) return;
+        nch = o.kin >> 2;
         nbase = o.W + wave * nch * 256;
     };
     if (op0 > 0) {  // decoder.predict: start behind REPARAM with z (already in z_out) as the activation
-        if (tid < PVN_ROWS)
-            for (int k = 0; k < Kz; ++k) cur[tid * PVN_LD + k] = z_out[(rb + tid) * Kz + k];
+        for (int i = tid; i < PVQ_ROWS * Kz; i += PVQ_THREADS) cur[i] = z_out[(rb + (i & 3)) * Kz + (i >> 2)];
         __syncthreads();
     }
     PvFwdOp op = pvn_get_op<PvFwdOp>(ops_s, op0);
+    PvW128 wnext;
     aim(op);
-    pvn_prefetch_plain(wnext, nbase, nch, lane);
+    pvq_prefetch_plain(wnext, nbase, nch, lane);
     PVN_DRAIN_VMEM();
-    for (int i = op0; i < nops; ++i) {
+    // One op: wcur = its B operands (loaded during the previous op), wnext = where the next op's go.  The loop below calls
+    // it twice per iteration with the two register sets swapped: copying one set into the other between ops (128 moves per
+    // lane and op) was a tenth of the chain's time.
+    auto step = [&](const PvW128& wcur, PvW128& wnext, const int i) __attribute__((always_inline)) {
         PVN_T(i * 8 + 0);
-        const PvW32 wcur = wnext;
-        // this op's bias: issued here, complete at the drain behind the MFMAs (op.b is never null)
-        const float bcur = pvn_g(op.b)[n0 < op.nout ? n0 + n : 0];
+        const int N = op.nout;
+        // this op's bias: issued here, complete at the drain behind the matrix instructions (op.b is never null)
+        const float bcur = pvn_g(op.b)[n < N ? n : 0];
         const PvFwdOp nx = i + 1 < nops ? pvn_get_op<PvFwdOp>(ops_s, i + 1) : op;
         if (i + 1 < nops) aim(nx);
         else { nbase = P; nch = 1; }
-        const int N = op.nout;
         PVN_T(i * 8 + 1);
         if (op.kind == PVN_REPARAM) {
-            pvn_prefetch_plain(wnext, nbase, nch, lane);
+            pvq_prefetch_plain(wnext, nbase, nch, lane);
             PVN_DRAIN_VMEM();
-            // cur holds the heads output: cols [0,K) = z_mean, [K,2K) = z_log_var; nxt gets z (padded to Kz)
-            if (tid < PVN_ROWS) {
-                const int lr = tid, b = rb + tid;  // row in LDS, row of the batch
-                float acc = 0.f;
-                for (int k = 0; k < Kz; ++k) {  // (cur and nxt are different buffers)
-                    float zz = 0.f;
-                    if (k < K) {
-                        const float mu = cur[lr * PVN_LD + k], sv = cur[lr * PVN_LD + K + k];
-                        const float es = expf(sv);
-                        zz = mu + es * eps[b * K + k];  // exp(s), not exp(s/2): popvae.py:389
-                        acc += 1.f + sv - mu * mu - es;
-                    }
-                    nxt[lr * PVN_LD + k] = zz;
-                    z_out[b * Kz + k] = zz;
+            // cur holds the heads output: k in [0,K) = z_mean, [K,2K) = z_log_var; nxt gets z (padded to Kz).  One (k, row)
+            // pair per thread; the KL terms meet in LDS and are summed per row in k order.
+            float* klt = nxt + Kz * PVQ_ROWS;  // [K][rows], behind z: the next op (contraction length Kz) never reads it
+            for (int i2 = tid; i2 < PVQ_ROWS * Kz; i2 += PVQ_THREADS) {
+                const int k = i2 >> 2, r = i2 & 3, b = rb + r;
+                float zz = 0.f;
+                if (k < K) {
+                    const float mu = cur[k * PVQ_ROWS + r], sv = cur[(K + k) * PVQ_ROWS + r];
+                    const float es = expf(sv);
+                    zz = mu + es * eps[b * K + k];  // exp(s), not exp(s/2): popvae.py:389
+                    klt[k * PVQ_ROWS + r] = 1.f + sv - mu * mu - es;
                 }
-                kl_out[b] = -0.5f * acc;
+                nxt[i2] = zz;
+                z_out[b * Kz + k] = zz;
             }
-        } else if (n0 < N) {
-            f32x4 acc[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+            pvn_lds_barrier();
+            if (tid < PVQ_ROWS) {
+                float acc = 0.f;
+                for (int k = 0; k < K; ++k) acc += klt[k * PVQ_ROWS + tid];
+                kl_out[rb + tid] = -0.5f * acc;
+            }
+        } else if (wave * 64 < N) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             if (op.kind == PVN_BIAS_ACT) {
+                if (n < N) {
 #pragma unroll
-                for (int t = 0; t < PVN_NT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[t][r] = P[(rb + 16 * t + 4 * q + r) * N + n0 + n];
-                pvn_prefetch_plain(wnext, nbase, nch, lane);
-                PVN_DRAIN_VMEM();
+                    for (int r = 0; r < PVQ_ROWS; ++r) acc[r] = P[(rb + r) * N + n];
+                }
+                pvq_prefetch_plain(wnext, nbase, nch, lane);
+            PVN_DRAIN_VMEM();
             } else {
-                const int ks = op.kin >> 2;
-                const float* a0 = cur + n * PVN_LD + q * ks;
-                PVN_SWITCH(ks, (pvn_mma<S_>(acc, a0, wcur, wnext, nbase, nch, lane)));
+                PVQ_SWITCH(op.kin, (acc = pvq_mma<C_>(cur + lane, wcur, wnext, nbase, nch, lane)));
                 PVN_DRAIN_VMEM();
             }
 #ifdef PVN_TRACE
-            asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]));
+            asm volatile("s_nop 0" ::"v"(acc));
             PVN_T(i * 8 + 2);
 #endif
+            if (n < N) {
+                f32x4 y;
 #pragma unroll
-            for (int t = 0; t < PVN_NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int lr = 16 * t + 4 * q + r;
-                    const float x = acc[t][r] + bcur;
-                    const float y = op.act == PV_ACT_ELU ? pv_elu(x) : x;
-                    nxt[lr * PVN_LD + n0 + n] = y;
-                    pvn_g(op.out)[(rb + lr) * N + n0 + n] = y;
+                for (int r = 0; r < PVQ_ROWS; ++r) {
+                    const float x = acc[r] + bcur;
+                    y[r] = op.act == PV_ACT_ELU ? pv_elu(x) : x;
                 }
+                *reinterpret_cast<f32x4*>(nxt + PVQ_ROWS * n) = y;
+#pragma unroll
+                for (int r = 0; r < PVQ_ROWS; ++r) pvn_g(op.out)[(rb + r) * N + n] = y[r];
+            }
         } else {
-            pvn_prefetch_plain(wnext, nbase, nch, lane);
+            pvq_prefetch_plain(wnext, nbase, nch, lane);
             PVN_DRAIN_VMEM();
         }
         PVN_T(i * 8 + 3);
@@ -348,21 +335,26 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
         cur = nxt;
         nxt = t_;
         op = nx;
+    };
+    PvW128 wother;
+    for (int i = op0; i < nops; i += 2) {
+        step(wnext, wother, i);
+        if (i + 1 < nops) step(wother, wnext, i + 1);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, part 1 -- the dependency chain on one CU: loss finalisation, then per layer (reverse order)
+// backward, part 1 -- the dependency chain: loss finalisation, then per layer (reverse order)
 //   dpre = dY * act'(Y)  (saved to global for part 2),  dIn = dpre * W^T  -> dY of the next op.
 // Ops: decoder layers D..1, REPARAM (dz -> dmu, ds), heads, encoder layers D..2, FIRST_BIAS (dpre1 + b1 Adam).
-// dY of the first op = xch[0 .. 32*W0): the all-reduced decoder feedback; xch[32*W0] = summed BCE.
-// Same structure as the forward: wave w owns the 16 columns [16w, 16w + 16) of dIn, and the epilogue of op i turns
-// its tile of dIn straight into the NEXT op's dpre (times act'(Y), rows beyond the batch zeroed), in LDS for the
+// dY of the first op = xch[0 .. rows*W0): the all-reduced decoder feedback; xch[rows*W0] = summed BCE.
+// Same structure as the forward: lane l of wave h owns column 64 h + l of dIn for the worker's four rows, and the epilogue of
+// op i turns it straight into the NEXT op's dpre (times act'(Y), rows beyond the batch zeroed), in LDS for the
 // chain and in global memory for part 2.  The weights are only READ here; part 2 (pvk_narrow_adam, one wave per
 // 32x32 weight block, spread over the chip) forms dW = in^T * dpre and applies Adam.
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __restrict__ ops, int nops,
+__global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_bwd(const PvBwdOp* __restrict__ ops, int nops,
                                                               const float* __restrict__ xch, int W0,
                                                               const float* __restrict__ kl,
                                                               const float* __restrict__ eps,
@@ -371,17 +363,17 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                                                               float* __restrict__ out3, int update, int nworkers) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cur = smem;
-    float* nxt = smem + 32 * PVN_LD;
-    int* ops_s = reinterpret_cast<int*>(smem + 2 * 32 * PVN_LD);
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, q = lane >> 4;
-    const int n0 = wave * 16;
-    const int rb = PVN_ROWS * (int)blockIdx.x;  // first batch row of this worker
+    float* nxt = smem + PVQ_LDA;
+    int* ops_s = reinterpret_cast<int*>(smem + 2 * PVQ_LDA);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int n = wave * 64 + lane;
+    const int rb = PVQ_ROWS * (int)blockIdx.x;  // first batch row of this worker
     if ((int)blockIdx.x >= nworkers) {
-        const int p = (int)(blockIdx.x >> 3) - 1;
-        if (update && blockIdx.x >= 8 && (int)(blockIdx.x & 7) < nworkers && p >= 0 && p < nops) {
+        const int p = ((int)blockIdx.x - nworkers) >> 3;
+        if (update && p < nops) {
             const PvBwdOp op = ops[p];
-            if (op.kind == PVN_DENSE) pvn_warm_l2(op.Wb, op.kin * op.nout, tid);
-            if (op.kind != PVN_REPARAM && op.act == PV_ACT_ELU) pvn_warm_l2(op.Y, 32 * op.nout, tid);
+            if (op.kind == PVN_DENSE) pvn_warm_l2(op.Wb, (int)pvn_wb_floats(op.kin, op.nout), tid);
+            if (op.kind != PVN_REPARAM && op.act == PV_ACT_ELU) pvn_warm_l2(op.Y, PVQ_ROWS * nworkers * op.nout, tid);
         }
         return;
     }
@@ -390,7 +382,7 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     const float inv_b = st->inv_b;
 
     if (blockIdx.x == 0 && tid == 0) {  // loss = mean_b(recon + kl) (popvae.py:423)
-        float sr = xch[16 * nworkers * W0], sk = 0.f;  // the recon sum sits behind the rows of the pass
+        float sr = xch[PVQ_ROWS * nworkers * W0], sk = 0.f;  // the recon sum sits behind the rows of the pass
         for (int b = 0; b < nrows; ++b) sk += kl[b];
         out3[0] = (sr + sk) * inv_b;
         out3[1] = sr * inv_b;
@@ -399,119 +391,103 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     if (!update) return;
     __syncthreads();
 
-    PvW32 wnext;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) wnext.lo[s] = wnext.hi[s] = 0.f;
-    // B operands of op o: lane (k = n, q) of wave w needs the run W[16w + k][q * ks + s], s < ks = nout / 4
+    // B operands of op o: lane l of wave h needs row 64 h + l of W (input unit k), all nout entries of it
     const float* nbase = xch;
     int nch = 1;
     auto aim = [&](const PvBwdOp& o) {
         nbase = xch; nch = 1;
-        if (o.kind != PVN_DENSE || n0 >= o.kin) return;
-        nch = o.nout >> 4;
+        if (o.kind != PVN_DENSE || wave * 64 >= o.kin) return;
+        nch = o.nout >> 2;
         nbase = o.Wb + wave * nch * 256;
     };
     PvBwdOp op = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, 0);
+    PvW128 wnext;
     aim(op);
-    pvn_prefetch_plain(wnext, nbase, nch, lane);
-    PVN_DRAIN_VMEM();
+    pvq_prefetch_plain(wnext, nbase, nch, lane);
     {   // dpre of the first op from the exchanged decoder feedback
-        if (n0 < W0) {
-            float xv[PVN_NT][4], yv[PVN_NT][4];
+        if (n < W0) {
+            float xv[PVQ_ROWS], yv[PVQ_ROWS];
 #pragma unroll
-            for (int t = 0; t < PVN_NT; ++t)
+            for (int r = 0; r < PVQ_ROWS; ++r) {
+                xv[r] = xch[(rb + r) * W0 + n];
+                yv[r] = pvn_g(op.Y)[(rb + r) * W0 + n];
+            }
+            f32x4 dv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int b = rb + 16 * t + 4 * q + r;
-                    xv[t][r] = xch[b * W0 + n0 + n];
-                    yv[t][r] = pvn_g(op.Y)[b * W0 + n0 + n];
-                }
-#pragma unroll
-            for (int t = 0; t < PVN_NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int lr = 16 * t + 4 * q + r, b = rb + lr;
-                    float d = b < nrows ? xv[t][r] : 0.f;
-                    if (op.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[t][r]);
-                    cur[lr * PVN_LD + n0 + n] = d;
-                    pvn_g(op.dpre)[b * W0 + n0 + n] = d;
-                }
+            for (int r = 0; r < PVQ_ROWS; ++r) {
+                float d = rb + r < nrows ? xv[r] : 0.f;
+                if (op.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[r]);
+                dv[r] = d;
+                pvn_g(op.dpre)[(rb + r) * W0 + n] = d;
+            }
+            *reinterpret_cast<f32x4*>(cur + PVQ_ROWS * n) = dv;
         }
     }
-    __syncthreads();
+    PVN_DRAIN_VMEM();
+    pvn_lds_barrier();
 
-    for (int i = 0; i < nops; ++i) {
+    // (two register sets in alternation, as in the forward)
+    auto step = [&](const PvW128& wb, PvW128& wnext, const int i) __attribute__((always_inline)) {
         PVN_T(128 + i * 8 + 0);
-        const PvW32 wb = wnext;
-        // dpre1 is in global memory by now (the previous op's epilogue), for the wide encoder backward and for
-        // pvk_narrow_adam, which also sums it over the batch for b1 (the rows are spread over the workers here)
-        if (op.kind == PVN_FIRST_BIAS) break;
         const PvBwdOp nx = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, i + 1);  // the table always ends with FIRST_BIAS
         aim(nx);
         if (op.kind == PVN_REPARAM) {
-            pvn_prefetch_plain(wnext, nbase, nch, lane);
+            pvq_prefetch_plain(wnext, nbase, nch, lane);
             PVN_DRAIN_VMEM();
-            // cur = dz [32][Kz]; result: dpre of the heads op [32][Kh] (cols [0,K) dmu, [K,2K) ds, rest 0)
-            if (tid < PVN_ROWS) {
-                const int lr = tid, b = rb + tid;  // row in LDS, row of the batch
-                const bool valid = b < nrows;
-                for (int k = 2 * K; k < Kh; ++k) {
-                    nxt[lr * PVN_LD + k] = 0.f;
+            // cur = dz [Kz][rows]; result: dpre of the heads op [Kh][rows] (k in [0,K) dmu, [K,2K) ds, rest 0)
+            for (int i2 = tid; i2 < PVQ_ROWS * Kh; i2 += PVQ_THREADS) {  // one (k, row) pair per thread
+                const int k = i2 >> 2, r = i2 & 3, b = rb + r;
+                if (k >= 2 * K) {
+                    nxt[i2] = 0.f;
                     pvn_g(nx.dpre)[b * Kh + k] = 0.f;
-                }
-                for (int k = 0; k < K; ++k) {  // (cur and nxt are different buffers)
+                } else if (k < K) {  // (cur and nxt are different buffers)
                     float dmu = 0.f, dsv = 0.f;
-                    if (valid) {
+                    if (b < nrows) {
                         const float mu = heads[b * Kh + k], s = heads[b * Kh + K + k];
-                        const float es = expf(s), d = cur[lr * PVN_LD + k];
+                        const float es = expf(s), d = cur[k * PVQ_ROWS + r];
                         dmu = d + mu * inv_b;
                         dsv = d * eps[b * K + k] * es + 0.5f * (es - 1.f) * inv_b;
                     }
-                    nxt[lr * PVN_LD + k] = dmu;
-                    nxt[lr * PVN_LD + K + k] = dsv;
+                    nxt[k * PVQ_ROWS + r] = dmu;
+                    nxt[(K + k) * PVQ_ROWS + r] = dsv;
                     pvn_g(nx.dpre)[b * Kh + k] = dmu;
                     pvn_g(nx.dpre)[b * Kh + K + k] = dsv;
                 }
             }
-        } else if (n0 < op.kin) {
-            const int Kin = op.kin, ks = op.nout >> 2;
+        } else if (wave * 64 < op.kin) {
+            const int Kin = op.kin;
             const bool to_dpre = nx.kind != PVN_REPARAM;  // REPARAM consumes the raw dz
-            float yv[PVN_NT][4];
-            if (to_dpre && nx.act == PV_ACT_ELU) {
+            const bool mine = n < Kin;
+            float yv[PVQ_ROWS];
+            if (mine && to_dpre && nx.act == PV_ACT_ELU) {
 #pragma unroll
-                for (int t = 0; t < PVN_NT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) yv[t][r] = pvn_g(nx.Y)[(rb + 16 * t + 4 * q + r) * Kin + n0 + n];
+                for (int r = 0; r < PVQ_ROWS; ++r) yv[r] = pvn_g(nx.Y)[(rb + r) * Kin + n];
             }
-            f32x4 acc[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
-            const float* a0 = cur + n * PVN_LD + q * ks;
+            f32x4 acc;
             PVN_T(128 + i * 8 + 1);
-            PVN_SWITCH(ks, (pvn_mma<S_>(acc, a0, wb, wnext, nbase, nch, lane)));
+            PVQ_SWITCH(op.nout, (acc = pvq_mma<C_>(cur + lane, wb, wnext, nbase, nch, lane)));
 #ifdef PVN_TRACE
-            asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]));
+            asm volatile("s_nop 0" ::"v"(acc));
             PVN_T(128 + i * 8 + 5);
 #endif
             PVN_DRAIN_VMEM();
             PVN_T(128 + i * 8 + 2);
+            if (mine) {
+                f32x4 dv;
 #pragma unroll
-            for (int t = 0; t < PVN_NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int lr = 16 * t + 4 * q + r, b = rb + lr;
-                    float d = acc[t][r];
+                for (int r = 0; r < PVQ_ROWS; ++r) {
+                    float d = acc[r];
                     if (to_dpre) {
-                        if (nx.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[t][r]);
-                        if (b >= nrows) d = 0.f;
-                        pvn_g(nx.dpre)[b * Kin + n0 + n] = d;
+                        if (nx.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[r]);
+                        if (rb + r >= nrows) d = 0.f;
+                        pvn_g(nx.dpre)[(rb + r) * Kin + n] = d;
                     }
-                    nxt[lr * PVN_LD + n0 + n] = d;
+                    dv[r] = d;
                 }
+                *reinterpret_cast<f32x4*>(nxt + PVQ_ROWS * n) = dv;
+            }
         } else {
-            pvn_prefetch_plain(wnext, nbase, nch, lane);
+            pvq_prefetch_plain(wnext, nbase, nch, lane);
             PVN_DRAIN_VMEM();
         }
         PVN_T(128 + i * 8 + 3);
@@ -521,6 +497,15 @@ __global__ __launch_bounds__(PVN_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
         cur = nxt;
         nxt = t_;
         op = nx;
+    };
+    // dpre1 is in global memory once the op before FIRST_BIAS has run (its epilogue), for the wide encoder backward and
+    // for pvk_narrow_adam, which also sums it over the batch for b1 (the rows are spread over the workers here)
+    PvW128 wother;
+    for (int i = 0; i < nops; i += 2) {
+        if (op.kind == PVN_FIRST_BIAS) break;
+        step(wnext, wother, i);
+        if (op.kind == PVN_FIRST_BIAS) break;
+        step(wother, wnext, i + 1);
     }
 }
 
@@ -650,20 +635,22 @@ __global__ __launch_bounds__(64) void pvk_narrow_adam_bias(const PvBwdOp* __rest
 }
 
 // Rebuilds the operand-order copies from the Keras-layout kernels (after set_weights / init / restore).  grid = (16, n_ops),
-// 256 threads; destination-ordered, so the writes are coalesced.
+// 256 threads; destination-ordered, so the writes are coalesced.  Columns beyond the layer are written as zeros.
 __global__ __launch_bounds__(256) void pvk_narrow_pack(const PvBwdOp* __restrict__ ops) {
     const PvBwdOp op = ops[blockIdx.y];
     if (op.kind != PVN_DENSE || !op.Wf) return;
-    const int N = op.nout, Kin = op.kin, total = N * Kin;
-    for (int d = blockIdx.x * 256 + threadIdx.x; d < total; d += gridDim.x * 256) {
-        const int e = d & 3, lane = (d >> 2) & 63, rest = d >> 8, n = lane & 15, q = lane >> 4;
-        {   // forward copy: rest = w * (Kin / 16) + c
-            const int nch = Kin >> 4, w = rest / nch, c = rest - w * nch;
-            op.Wf[d] = op.W[(q * (Kin >> 2) + 4 * c + e) * N + 16 * w + n];
-        }
-        {   // backward copy: rest = w * (N / 16) + c
-            const int nch = N >> 4, w = rest / nch, c = rest - w * nch;
-            op.Wb[d] = op.W[(16 * w + n) * N + q * (N >> 2) + 4 * c + e];
-        }
+    const int N = op.nout, Kin = op.kin;
+    const int nf = (int)pvn_wf_floats(Kin, N), nb = (int)pvn_wb_floats(Kin, N);
+    for (int d = blockIdx.x * 256 + threadIdx.x; d < nf; d += gridDim.x * 256) {
+        // forward copy: d = ((h * Kin/4 + c) * 64 + l) * 4 + e  <-  W[4c + e][64 h + l]
+        const int e = d & 3, l = (d >> 2) & 63, rest = d >> 8, nch = Kin >> 2, h = rest / nch, c = rest - h * nch;
+        const int col = 64 * h + l;
+        op.Wf[d] = col < N ? op.W[(4 * c + e) * N + col] : 0.f;
+    }
+    for (int d = blockIdx.x * 256 + threadIdx.x; d < nb; d += gridDim.x * 256) {
+        // backward copy: d = ((h * N/4 + c) * 64 + l) * 4 + e  <-  W[64 h + l][4c + e]
+        const int e = d & 3, l = (d >> 2) & 63, rest = d >> 8, nch = N >> 2, h = rest / nch, c = rest - h * nch;
+        const int k = 64 * h + l;
+        op.Wb[d] = k < Kin ? op.W[k * N + 4 * c + e] : 0.f;
     }
 }

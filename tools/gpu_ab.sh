@@ -1,7 +1,16 @@
 #!/bin/bash
-# A/B of two engine builds in one call: tools/gpu_ab.sh libA.so libB.so [shapes...]; NOTIMING kbench, alternating
-export TMPDIR=/tmp NOTIMING=1
-A=$1; B=$2; shift 2
-for sh in "$@"; do for rep in 1 2; do for v in $A $B; do
-  echo "$sh $(basename $v): $(PVAE_LIB=$PWD/$v timeout -k 10 100 python3 tools/kbench.py $sh 71 2>/dev/null | sed -n 1p)"
-done; done; done
+# A/B of engine builds in one process sequence on one box: tools/gpu_ab.sh libA.so libB.so ...  (kbench without events, 3 rounds interleaved)
+set -o pipefail
+mkdir -p gpurun_out/ab
+for round in 1 2 3; do
+  for lib in "$@"; do
+    for wl in C2 C4; do
+      echo -n "$(basename $lib) r$round: "
+      PVAE_LIB=$lib NOTIMING=1 timeout -k 10 120 python3 tools/kbench.py $wl 142 | sed -n '1p;$p' | tr '\n' ' ' || exit 1
+      echo
+    done
+    echo -n "$(basename $lib) r$round: "
+    PVAE_LIB=$lib NOTIMING=1 timeout -k 10 120 python3 tools/kbench.py C4 40 128 | sed -n '1p;$p' | tr '\n' ' ' || exit 1
+    echo
+  done
+done
