@@ -21,6 +21,9 @@ import time
 import numpy as np
 
 
+GRID_TIMINGS = []  # (width, depth, seconds, epochs) per --search_network_sizes cell of the last run in this process (measurement)
+
+
 def build_parser():
     p = argparse.ArgumentParser()
     p.add_argument("--infile", help="path to input genotypes in vcf (.vcf | .vcf.gz), zarr, or .popvae.hdf5 format.")
@@ -213,7 +216,7 @@ def main(argv=None):
                                         args.patience, n_snps, out=args.out,
                                         perm_fn_factory=lambda i: F.default_perm_fn(None if shuffle_seed is None
                                                                                     else shuffle_seed + 1 + i),
-                                        rank=rank, world=world, gather=gather, log=log)
+                                        rank=rank, world=world, gather=gather, log=log, timings=GRID_TIMINGS)
         log("best parameters:\nwidth = " + str(width) + "\ndepth = " + str(depth))
 
     if world > 1:

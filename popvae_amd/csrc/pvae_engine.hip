@@ -95,6 +95,9 @@ struct pvae_engine {
     float *dA = nullptr, *dB = nullptr, *dpre1 = nullptr, *dheads = nullptr, *dz = nullptr;
     uint64_t* Xt = nullptr;
     uint64_t* Xr = nullptr;    // the gathered (untransposed) words of the batch: operand order of pvk_enc_fwd
+    uint64_t* Xrn = nullptr;   // the same for the NEXT batch of the epoch loop (one tile): operand of the fused forward in pvk_enc_bwd
+    uint64_t* Xt2 = nullptr;   // second transposed-batch buffer (one tile): the epoch loop's step head gathers the NEXT batch
+    uint64_t* xt_act = nullptr;  // the transposed batch the decoder / encoder-backward launches read (Xt, or Xt2 in the epoch loop)
     float* probs = nullptr;  // decoder.predict staging [32][L], allocated on first pvae_decode
     float* enc_out = nullptr;  // encoder.predict staging: per 32-row batch [32][Kh] heads + [32][Kz] z, read back once
     int64_t enc_out_cap = 0;   // in floats
@@ -117,6 +120,11 @@ struct pvae_engine {
     int ts4 = 0;
     // fused narrow stack (width <= 128): op tables in device memory
     bool fused_narrow = false, narrow_warm = true, fuse_fwd = false;
+    // epoch loop: the step head gathers the NEXT batch (transposed copy + compact words) and the forward fused into the wide
+    // encoder backward reads the compact words.  Takes the kernel's HBM traffic from 1.03x to 1.011x of the algorithmic bytes
+    // (profiles/r03_exp_xrn_pmc_traffic_C4.json) but not its time (546-547 us against 548), and the head writes 8 MB more per
+    // step at 1M SNPs (8.2 -> 11.7 us): a net loss of ~2 us per step, so it is opt-in (PVAE_XRN=1).
+    bool use_xrn = false;
     bool narrow_pack_dirty = true;  // the operand-order copies lag behind the Keras-layout kernels
     PvFwdOp* d_fwd_ops = nullptr;
     PvBwdOp *d_bwd_ops = nullptr, *d_bwd_ops_grad = nullptr;
@@ -491,6 +499,7 @@ int stage_a(pvae_engine* e, int row_offset, bool need_xt, bool fwd_done = false,
     if (!e->geno) return set_err(e, -3, "no genotypes loaded (pvae_load_genotypes)");
     if (need_xt) {
         Timer t(e, C_GATHER);
+        e->xt_act = e->Xt;
         int pairs = (e->nblk + 1) / 2;
         hipLaunchKernelGGL(pvk_gather_transpose, dim3((pairs + 3) / 4), dim3(256), 0, e->stream, e->geno, e->row_bytes,
                            e->d_rows, e->st, row_offset, e->nblk, e->Xt, fwd_done ? (uint64_t*)nullptr : e->Xr);
@@ -656,7 +665,7 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
         if (mode == 4 && (!agV || !agC)) return set_err(e, -6, "train-with-accumulated-gradients step without a gradient dump");
 #define PV_DEC_LAUNCH(KERN, THREADS, LDS)                                                                                      \
     hipLaunchKernelGGL(KERN, dim3(e->dec_wgs), dim3(THREADS), LDS, e->stream, aV, amV, avV, aV2, amV2, avV2, acb, amC, avC, gD, \
-                       e->Xt, e->nblk, (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4, agV, agC)
+                       e->xt_act, e->nblk, (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4, agV, agC)
 #define PV_DEC_MODES(K3, THREADS, LDS)                                                     \
     do {                                                                                   \
         if (mode == 0) PV_DEC_LAUNCH((K3(1, PV_MODE_TRAIN)), THREADS, LDS);                \
@@ -676,11 +685,11 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
 #define PV_K3(TR, MD) pvk_dec<N_, TR, MD>
             if (mode == 0 && e->dec2_wgs) {  // plain training pass: block-column split
                 PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_dec2<N_>, dim3(e->dec2_wgs), dim3(PvDec2<N_>::NW * 64), PvDec2<N_>::lds(),
-                                                      e->stream, aV, amV, avV, aV2, amV2, avV2, acb, amC, avC, gD, e->Xt, e->nblk,
+                                                      e->stream, aV, amV, avV, aV2, amV2, avV2, acb, amC, avC, gD, e->xt_act, e->nblk,
                                                       (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4));
             } else if (mode == 1) {  // read-only pass: small LDS footprint, its own (larger) grid
                 PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec<N_, 0, PV_MODE_TRAIN>), dim3(e->dec_eval_wgs), dim3(256), lds_dec_eval(N_),
-                                                      e->stream, aV, amV, avV, aV2, amV2, avV2, acb, amC, avC, gD, e->Xt, e->nblk,
+                                                      e->stream, aV, amV, avV, aV2, amV2, avV2, acb, amC, avC, gD, e->xt_act, e->nblk,
                                                       (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4, agV, agC));
             } else {
                 PV_DISPATCH_NWB(e, PV_DEC_MODES(PV_K3, 256, lds_dec(N_)));
@@ -701,7 +710,8 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
     return 0;
 }
 
-int enc_bwd_launch(pvae_engine* e, int km, bool fuse = false, int next_off = 0, int next_n = 0, const PvBwdOp* adam_ops = nullptr) {
+int enc_bwd_launch(pvae_engine* e, int km, bool fuse = false, int next_off = 0, int next_n = 0, const PvBwdOp* adam_ops = nullptr,
+                   const uint64_t* Xn = nullptr) {
     int rc;
     Timer t(e, C_ENC_BWD);
     const uint8_t* nog = nullptr;
@@ -715,26 +725,26 @@ int enc_bwd_launch(pvae_engine* e, int km, bool fuse = false, int next_off = 0, 
         if (!e->W1.g && (rc = allocf(e, &e->W1.g, e->W1.n))) return rc;
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_GRAD, 0>), dim3(e->encb_wgs), dim3(256),
                                               lds_enc_bwd(e->Wp), e->stream, e->W1.w, (float*)nullptr, (float*)nullptr,
-                                              (float*)nullptr, e->W1.g, (float*)nullptr, e->dpre1, e->Wp, e->Xt, e->nblk,
+                                              (float*)nullptr, e->W1.g, (float*)nullptr, e->dpre1, e->Wp, e->xt_act, e->nblk,
                                               e->ngrp, e->st, e->adam, nog, (int64_t)0, nor, 0, 0, nof, e->ts4, nogw, noops, 0));
     } else if (km == PV_MODE_TRAIN_ACC) {
         if (!e->W1.g) return set_err(e, -6, "train-with-accumulated-gradients step without a gradient dump");
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN_ACC, 0>), dim3(e->encb_wgs), dim3(256),
                                               lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
-                                              e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam, nog,
+                                              e->W1.v2, e->dpre1, e->Wp, e->xt_act, e->nblk, e->ngrp, e->st, e->adam, nog,
                                               (int64_t)0, nor, 0, 0, nof, e->ts4, (const float*)e->W1.g, noops, 0));
         e->W1.swap();
     } else if (fuse) {
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 1>), dim3(e->encb_wgs + adam_wgs), dim3(256),
                                               lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
-                                              e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam,
+                                              e->W1.v2, e->dpre1, e->Wp, e->xt_act, e->nblk, e->ngrp, e->st, e->adam,
                                               (const uint8_t*)e->geno, e->row_bytes, (const int*)e->d_rows, next_off, next_n,
-                                              e->encpart, e->ts4, nogw, adam_ops, adam_units));
+                                              e->encpart, e->ts4, nogw, adam_ops, adam_units, Xn));
         e->W1.swap();
     } else {
         PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_enc_bwd<N_, PV_MODE_TRAIN, 0>), dim3(e->encb_wgs + adam_wgs), dim3(256),
                                               lds_enc_bwd(e->Wp), e->stream, e->W1.w, e->W1.m, e->W1.v, e->W1.w2, e->W1.m2,
-                                              e->W1.v2, e->dpre1, e->Wp, e->Xt, e->nblk, e->ngrp, e->st, e->adam, nog,
+                                              e->W1.v2, e->dpre1, e->Wp, e->xt_act, e->nblk, e->ngrp, e->st, e->adam, nog,
                                               (int64_t)0, nor, 0, 0, nof, e->ts4, nogw, adam_ops, adam_units));
         e->W1.swap();
     }
@@ -753,7 +763,8 @@ int ensure_grad_bufs(pvae_engine* e) {
 
 // stage C: loss, narrow backward (+Adam), wide encoder backward (+Adam).  mode: 0 train, 1 eval, 2 gradient dump,
 // 4 train on (this pass + dumped gradients)
-int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next_off = 0, int next_n = 0) {
+int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next_off = 0, int next_n = 0,
+            const uint64_t* Xn = nullptr) {
     int rc;
     const int km = mode == 2 ? PV_MODE_GRAD : mode == 4 ? PV_MODE_TRAIN_ACC : PV_MODE_TRAIN;
     if ((mode == 2 || mode == 4) && !e->d_bwd_ops_grad && (rc = ensure_grad_bufs(e))) return rc;
@@ -782,7 +793,7 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
         if ((rc = launch_check(e, "narrow_bwd"))) return rc;
         }
         if (mode == 1) return 0;
-        return enc_bwd_launch(e, km, fuse, next_off, next_n, ride ? table : nullptr);
+        return enc_bwd_launch(e, km, fuse, next_off, next_n, ride ? table : nullptr, Xn);
     }
     if (mode == 1) {  // evaluation: the loss scalars are all there is left to do
         hipLaunchKernelGGL(pvk_loss_final, dim3(1), dim3(64), 0, e->stream, e->xch1 + 32 * e->Wp, e->kl, e->st, d_out3);
@@ -837,7 +848,7 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
         }
         if ((rc = launch_check(e, "narrow_adam/bias_bwd"))) return rc;
     }
-    return enc_bwd_launch(e, km, fuse, next_off, next_n);
+    return enc_bwd_launch(e, km, fuse, next_off, next_n, nullptr, Xn);
 }
 
 int ensure_rows(pvae_engine* e, int64_t n) {
@@ -1392,6 +1403,11 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     HK(hipMemsetAsync(e->Xt, 0, e->T * e->Lp * sizeof(uint64_t), e->stream));
     HK(hipMalloc(&e->Xr, e->T * e->Lp * sizeof(uint64_t)));
     HK(hipMemsetAsync(e->Xr, 0, e->T * e->Lp * sizeof(uint64_t), e->stream));
+    HK(hipMalloc(&e->Xrn, e->Lp * sizeof(uint64_t)));
+    HK(hipMemsetAsync(e->Xrn, 0, e->Lp * sizeof(uint64_t), e->stream));
+    HK(hipMalloc(&e->Xt2, e->Lp * sizeof(uint64_t)));
+    HK(hipMemsetAsync(e->Xt2, 0, e->Lp * sizeof(uint64_t), e->stream));
+    e->xt_act = e->Xt;
 
     auto clampi = [](int64_t v, int64_t lo, int64_t hi) { return (int)std::min(hi, std::max(lo, v)); };
     CK(setup_kernel_attrs(e));
@@ -1477,6 +1493,7 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
         e->dec3_wgs = std::max(1, std::min(cus2, (e->nblk + spw - 1) / spw));
     }
     e->fuse_fwd = !getenv("PVAE_NO_FUSE_FWD");
+    e->use_xrn = getenv("PVAE_XRN") != nullptr;
     e->dgpart_cap = std::max((int64_t)std::max(e->dec_wgs, e->dec2_wgs) * 32 * e->Wp, (int64_t)e->dec3_wgs * 32 * e->T * e->Wp);
     CK(allocf(e, &e->dgpart, e->dgpart_cap));
     // one BCE sum per workgroup of whichever decoder kernel runs; pvk_dec_eval_mt<T, 1> leaves one per workgroup AND row tile
@@ -1530,7 +1547,7 @@ int pvae_destroy(pvae_engine* e) {
     for (auto p : e->dpre_bufs) hipFree(p);
     hipFree(e->probs);
     hipFree(e->enc_out);
-    hipFree(e->Xt); hipFree(e->Xr); hipFree(e->geno); hipFree(e->st); hipFree(e->d_rows); hipFree(e->d_ntotal); hipFree(e->d_counter);
+    hipFree(e->Xt); hipFree(e->Xr); hipFree(e->Xrn); hipFree(e->Xt2); hipFree(e->geno); hipFree(e->st); hipFree(e->d_rows); hipFree(e->d_ntotal); hipFree(e->d_counter);
     for (auto& ev : e->evs) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     for (auto& sl : e->slots) { if (sl.host) hipHostFree(sl.host); if (sl.ev) hipEventDestroy(sl.ev); }
     if (e->h_out3) hipHostFree(e->h_out3);
@@ -1749,6 +1766,8 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
     // batch size 32: the validation batches go through the read-only kernels T at a time, each with its own loss (one read
     // of the wide weights per T batches instead of one per batch)
     const bool mt_val = tp == 1 && B == 32 && e->T > 1 && e->fused_narrow && st_va > 1 && !getenv("PVAE_NO_MT_VAL");
+    bool xt_ready = false;  // the current batch was gathered by the previous step's head
+    int xt_par = 0;         // which of Xt / Xt2 holds (or will hold) the current batch
     for (int phase = 0; phase < 2 && tp == 1; ++phase) {
         const int steps = phase == 0 ? st_tr : st_va;
         if (!steps) continue;
@@ -1778,17 +1797,28 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
             }
             // per-step scalars + noise + batch gather (+ the sum of the first-layer partial tiles the previous step's wide
             // encoder backward left behind) in one launch
-            const int nred = fwd_done ? PV_REDUCE_GRID(32 * e->Wp) : 0;
-            hipLaunchKernelGGL(pvk_step_begin_gather, dim3(nred + ((e->nblk + 1) / 2 + 3) / 4 + 1), dim3(256), 0, e->stream, e->st,
+            // Two transposed-batch buffers in alternation: when the next batch's forward is fused into this step's wide encoder
+            // backward, this step's head gathers the NEXT batch (transposed copy + compact words) and the next step's head has
+            // nothing left to gather -- one gather per step either way, and the fused forward reads a compact array.
+            const int nred = fwd_done ? PV_REDUCE_GRID(32 * e->Wp) : 0, ngb = ((e->nblk + 1) / 2 + 3) / 4;
+            uint64_t *xt_cur = xt_par ? e->Xt2 : e->Xt, *xt_next = xt_par ? e->Xt : e->Xt2;
+            const bool pre = fuse && e->use_xrn;  // gather the next batch now
+            const int ngather = xt_ready ? 0 : ngb, ngather_next = pre ? ngb : 0;
+            hipLaunchKernelGGL(pvk_step_begin_gather, dim3(nred + ngather + ngather_next + 1), dim3(256), 0, e->stream, e->st,
                                (const int*)e->d_ntotal, B, s, phase == 0 ? 1 : 0, e->adam.b1, e->adam.b2, e->eps, 32 * e->K,
-                               e->cfg.seed, e->d_counter, e->geno, e->row_bytes, (const int*)e->d_rows, base + s * B, e->nblk, e->Xt,
-                               nred, (const float*)e->encpart, e->encb_parts, 32 * e->Wp, e->P);
+                               e->cfg.seed, e->d_counter, e->geno, e->row_bytes, (const int*)e->d_rows, base + s * B, e->nblk, xt_cur,
+                               nred, (const float*)e->encpart, e->encb_parts, 32 * e->Wp, e->P, ngather, ngather_next, next_off,
+                               next_n, xt_next, e->Xrn);
+            e->xt_act = xt_cur;
+            const uint64_t* xrn = pre ? e->Xrn : nullptr;
+            xt_ready = pre;
+            if (pre) xt_par ^= 1;
             if ((rc = launch_check(e, "step_begin/gen_eps/gather"))) return rc;
             if ((rc = stage_a(e, base + s * B, false, fwd_done, fwd_done))) return rc;
             if ((rc = shard_allreduce(e, 0))) return rc;
             if ((rc = stage_b(e, phase == 0 ? 0 : 1))) return rc;
             if ((rc = shard_allreduce(e, 1))) return rc;
-            if ((rc = stage_c(e, phase == 0 ? 0 : 1, e->d_loss + 3 * ((phase == 0 ? 0 : st_tr) + s), fuse, next_off, next_n)))
+            if ((rc = stage_c(e, phase == 0 ? 0 : 1, e->d_loss + 3 * ((phase == 0 ? 0 : st_tr) + s), fuse, next_off, next_n, xrn)))
                 return rc;
             fwd_done = fuse;
         }

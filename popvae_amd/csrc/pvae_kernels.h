@@ -1918,7 +1918,8 @@ __device__ __forceinline__ void pv_enc_bwd_train(const float* __restrict__ W1, c
                                                  const uint8_t* __restrict__ geno, int64_t row_bytes, const int* __restrict__ rows,
                                                  int next_off, int next_n, float* __restrict__ fpart, int ts,
                                                  const PvBwdOp* __restrict__ adam_ops, int adam_units, float* smem,
-                                                 const float* __restrict__ gW = nullptr) {
+                                                 const float* __restrict__ gW = nullptr, const uint64_t* __restrict__ Xn = nullptr) {
+    // Xn (FUSE): the next batch's words, gathered by the step head (pv_gather_raw_block); NULL: read from the resident matrix
     // MODE (chunks of a batch above 32 T rows): PV_MODE_GRAD stores / adds (PvStep.acc) 0.5 dW into the dump mWo (plain tiles) and
     // reads no weights at all; PV_MODE_TRAIN_ACC adds the dump gW to this pass's gradient before Adam.
     constexpr int WG_UNITS = NWB * 32;
@@ -1962,11 +1963,11 @@ __device__ __forceinline__ void pv_enc_bwd_train(const float* __restrict__ W1, c
         }
     };
     const uint8_t* nrow = nullptr;  // FUSE: lane c's sample of the next batch
-    if (FUSE && c < next_n) nrow = geno + (int64_t)rows[next_off + c] * row_bytes;
+    if (FUSE && !Xn && c < next_n) nrow = geno + (int64_t)rows[next_off + c] * row_bytes;
     auto words = [&](int blk_, uint64_t (&xw_)[T], uint64_t& xn_) {
 #pragma unroll
         for (int t = 0; t < T; ++t) xw_[t] = Xt[((int64_t)t * nblk + blk_) * 32 + c];
-        if (FUSE) xn_ = nrow ? *reinterpret_cast<const uint64_t*>(nrow + (int64_t)blk_ * 8) : 0ull;
+        if (FUSE) xn_ = Xn ? Xn[(int64_t)blk_ * 32 + c] : nrow ? *reinterpret_cast<const uint64_t*>(nrow + (int64_t)blk_ * 8) : 0ull;
     };
     Block bk[2];
     uint64_t xw[T] = {}, xn = 0;
@@ -2066,14 +2067,15 @@ __global__ __launch_bounds__(256, 2) void pvk_enc_bwd(const float* __restrict__ 
                                                    const uint8_t* __restrict__ geno, int64_t row_bytes,
                                                    const int* __restrict__ rows, int next_off, int next_n,
                                                    float* __restrict__ fpart, int ts, const float* __restrict__ gW,
-                                                   const PvBwdOp* __restrict__ adam_ops, int adam_units) {
+                                                   const PvBwdOp* __restrict__ adam_ops, int adam_units,
+                                                   const uint64_t* __restrict__ Xn = nullptr) {
     constexpr int WG_UNITS = NWB * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [ngrp][32][WG_UNITS]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
     PV_WT(1, 0);
     if constexpr (MODE == PV_MODE_TRAIN || T > 1) {  // several row tiles: the block-column sweep in every mode
         pv_enc_bwd_train<NWB, FUSE, T, MODE>(W1, mW, vW, W1o, mWo, vWo, dpre, ldp, Xt, nblk, ngrp, st, adam, geno, row_bytes, rows,
-                                          next_off, next_n, fpart, ts, adam_ops, adam_units, smem, gW);
+                                          next_off, next_n, fpart, ts, adam_ops, adam_units, smem, gW, Xn);
         PV_WT(1, 3);
         return;
     }
@@ -2268,15 +2270,26 @@ __global__ __launch_bounds__(256) void pvk_step_begin_gather(PvStep* st, const i
                                                              const uint8_t* __restrict__ geno, int64_t row_bytes,
                                                              const int* __restrict__ rows, int row_offset, int nblk,
                                                              uint64_t* __restrict__ Xt, int nred, const float* __restrict__ fpart,
-                                                             int nparts, int nP, float* __restrict__ P) {
+                                                             int nparts, int nP, float* __restrict__ P, int ngather, int ngather_next,
+                                                             int next_off, int next_n, uint64_t* __restrict__ Xt_next,
+                                                             uint64_t* __restrict__ Xrn) {
+    // blocks [0, nred): partial-tile sums; then ngather blocks (0 when the previous step's head already did it) that gather /
+    // transpose THIS batch into Xt; then ngather_next blocks that gather / transpose the NEXT batch (rows[next_off ..], next_n of
+    // them) into Xt_next and leave its words in Xrn, the compact operand of the forward fused into this step's wide encoder
+    // backward: from the resident matrix that kernel touched 32 cache lines per block and wave (8 bytes used of each; +3 % HBM
+    // traffic, profiles/r02_v6_pmc_traffic_C4.json), from Xrn it reads 256 contiguous bytes; last block: scalars + noise
     if ((int)blockIdx.x < nred) {
         pv_reduce_block(fpart, nparts, nP, 0.5f, P, nullptr, nullptr, blockIdx.x);
         return;
     }
     const int remaining = *n_total_ptr - step * batch;
     const int nrows = max(0, min(remaining, batch));
-    if (blockIdx.x + 1 < gridDim.x) {
+    if ((int)blockIdx.x < nred + ngather) {
         pv_gather_block(geno, row_bytes, rows, nrows, row_offset, nblk, Xt, nullptr, (int)blockIdx.x - nred);
+        return;
+    }
+    if ((int)blockIdx.x < nred + ngather + ngather_next) {
+        pv_gather_block(geno, row_bytes, rows, next_n, next_off, nblk, Xt_next, Xrn, (int)blockIdx.x - nred - ngather);
         return;
     }
     const int i = threadIdx.x;

@@ -224,10 +224,12 @@ def grid_paramsets(width_range, depth_range):
     return [[int(x), int(y)] for x in width_range for y in depth_range]
 
 
-def grid_fit_one(make_engine, width, depth, train, test, max_epochs, patience, perm_fn=None):
+def grid_fit_one(make_engine, width, depth, train, test, max_epochs, patience, perm_fn=None, timings=None):
     """One cell of the --search_network_sizes grid (popvae.py:284-369): quarter patience (a float),
-    quarter epochs, no checkpoint, min(val_loss) reported."""
+    quarter epochs, no checkpoint, min(val_loss) reported.  timings (a list, optional): gets (width, depth, seconds of the
+    cell incl. building the model, epochs run) appended -- measurement only, the reference's files do not carry it."""
     tmp_patience = patience / 4
+    t0 = time.time()
     eng = make_engine(width, depth)
     try:
         hist, _ = fit(eng, train, test, max_epochs=int(max_epochs / 4), patience=tmp_patience,
@@ -235,6 +237,8 @@ def grid_fit_one(make_engine, width, depth, train, test, max_epochs, patience, p
                       verbose=0)
     finally:
         eng.close()
+    if timings is not None:
+        timings.append((width, depth, time.time() - t0, len(hist["val_loss"])))
     return {"width": width, "depth": depth, "val_loss": float(np.min(hist["val_loss"]))}
 
 
@@ -252,7 +256,7 @@ def lpt_schedule(costs, n_workers):
 
 
 def grid_search(make_engine, width_range, depth_range, train, test, max_epochs, patience, n_snps, out=None,
-                perm_fn_factory=None, rank=0, world=1, gather=None, log=print):
+                perm_fn_factory=None, rank=0, world=1, gather=None, log=print, timings=None):
     """--search_network_sizes (popvae.py:275-380).  With world > 1 the cells are spread one network per GPU
     (task parallel, no data-path collective); ``gather(list) -> list of lists`` collects the per-rank results
     (e.g. ``torch.distributed.all_gather_object``).  Returns (rows in reference order, best width, best depth)."""
@@ -264,7 +268,7 @@ def grid_search(make_engine, width_range, depth_range, train, test, max_epochs, 
         w, d = paramsets[i]
         log(f"width={w}\ndepth={d}")
         pf = perm_fn_factory(i) if perm_fn_factory else None
-        local[i] = grid_fit_one(make_engine, w, d, train, test, max_epochs, patience, perm_fn=pf)
+        local[i] = grid_fit_one(make_engine, w, d, train, test, max_epochs, patience, perm_fn=pf, timings=timings)
     if world > 1:
         merged = {}
         for part in gather(local):

@@ -122,3 +122,35 @@ def test_cache_and_weight_files_through_the_cli(tmp_path, monkeypatch, capsys):
     # the second run starts from the first run's best weights: its first epoch is already far below a fresh model's
     assert float(h2[1][1]) < 0.9 * float(h1[1][1])
     assert os.path.exists(out2 + "_weights.hdf5")
+
+
+def test_network_size_grid_as_a_run(tmp_path, monkeypatch, capsys):
+    """BASELINE config 5 is `--search_network_sizes` over widths {32, 256, 512} x depths {3, 5, 8} (popvae.py:275-380): here the
+    same grid as a RUN through the command line on one GPU, at reduced size and epochs (200 samples x 20 k SNPs from a
+    .popvae.hdf5 cache; tools/grid_c5.py is the full-size run whose timings sit under profiles/): nine networks one after the
+    other, the three narrow-stack paths (op-table chain at width 32, per-layer kernels at 256 / 512) and both grouped decoder
+    kernels; _param_grid.csv in the reference's width-major row order with finite losses, then the final fit at the argmin."""
+    from popvae_amd.weights_io import write_popvae_cache
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    g = np.random.default_rng(5)
+    N, L = 200, 20_000
+    pop = np.arange(N) % 3
+    f = np.clip(np.clip(g.beta(.5, .5, L), .02, .98)[None] + 0.1 * g.normal(size=(3, L)), .02, .98)
+    dc = (g.binomial(2, f[pop]) * 0.5).astype(np.float64)
+    infile = str(tmp_path / "synth.popvae.hdf5")
+    write_popvae_cache(infile, dc, np.array([f"s{i:03d}" for i in range(N)], dtype=object))
+    out = str(tmp_path / "grid")
+    assert cli.main(["--infile", infile, "--out", out, "--seed", "42", "--max_epochs", "24", "--patience", "8",
+                     "--search_network_sizes", "--width_range", "32,256,512", "--depth_range", "3,5,8"]) == 0
+    rows = open(out + "_param_grid.csv").read().splitlines()
+    assert rows[0] == "width,depth,val_loss"
+    assert [tuple(int(x) for x in r.split(",")[:2]) for r in rows[1:]] == [(w, d) for w in (32, 256, 512) for d in (3, 5, 8)]
+    vals = np.array([float(r.split(",")[2]) for r in rows[1:]])
+    assert np.isfinite(vals).all() and (vals > 0).all()
+    log = capsys.readouterr().out
+    best = rows[1 + int(np.argmin(vals))].split(",")
+    assert f"width = {best[0]}\ndepth = {best[1]}" in log        # popvae.py:375-380
+    assert len(cli.GRID_TIMINGS) >= 9 and all(ep <= 6 for _, _, _, ep in cli.GRID_TIMINGS[-9:])  # int(24 / 4) epochs per cell
+    lat = open(out + "_latent_coords.txt").read().splitlines()
+    assert len(lat) == 1 + N

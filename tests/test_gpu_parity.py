@@ -148,13 +148,55 @@ def test_adam_training_steps_match_oracle(L, W, D):
         assert abs(lg - lo) <= RTOL * abs(lo), (step, lg, lo)
     # Adam's first steps move every weight by ~lr regardless of gradient scale, so compare the UPDATE
     # (w_after - w_before) relative to lr*steps, plus the moments against the oracle's.
+    # (measured, tools/adam_tol_probe.py: weights within 8e-6, first moments within 2e-5 of the oracle's after these five steps --
+    # 1.9e-4 at depth 20, where 40 layers amplify the float32 rounding of the trajectory -- second moments within 3.4e-5)
     for i, (a, b, b0) in enumerate(zip(e.get_weights(), wo, w)):
         upd_err = np.abs(a.astype(np.float64) - b).max()
-        assert upd_err <= 2e-2 * 5e-3, (i, upd_err)  # 2% of the 5*lr travel
+        assert upd_err <= 4e-3 * 5e-3, (i, upd_err)  # 0.4 % of the 5*lr travel
+    m_tol = 1e-4 if D < 20 else 4e-4
     for i, (a, b) in enumerate(zip(e.get_moments(0), opt.m)):
-        assert _relerr(a, b) <= 1e-3, ("m", i, _relerr(a, b))
+        assert _relerr(a, b) <= m_tol, ("m", i, _relerr(a, b))
     for i, (a, b) in enumerate(zip(e.get_moments(1), opt.v)):
-        assert _relerr(a, b) <= 1e-3, ("v", i, _relerr(a, b))
+        assert _relerr(a, b) <= 1e-4, ("v", i, _relerr(a, b))
+    e.close()
+
+
+@pytest.mark.parametrize("L,W,D,B", [(1000, 128, 3, 32), (700, 512, 2, 32), (900, 256, 3, 32), (1100, 96, 2, 32), (1000, 128, 3, 96)])
+def test_adam_update_step_by_step_from_the_engines_own_state(L, W, D, B):
+    """The fused Adam arithmetic itself (pv_adam: v_sqrt_f32 / v_rcp_f32), isolated from trajectory drift: before each of five
+    train steps the oracle is put on the ENGINE's float32 weights and moments, so that its gradient is the gradient of exactly the
+    state the engine steps from; afterwards every tensor's first moment must be m + (g - m)(1 - beta_1), its second moment
+    v + (g^2 - v)(1 - beta_2) and its weight w - alpha m' / (sqrt(v') + eps) (K7) -- moments to 1e-4 of the tensor's largest
+    entry, the update to 1e-4 of the learning rate plus the float32 rounding of the stored weight."""
+    N, K = max(64, B + 20), 2
+    dc, w = _problem(N, L, W, D, K, seed=17)
+    e = _mk(dc, w, W, D, K, B=B)
+    g = np.random.default_rng(6)
+    lr, b1, b2, eps_adam = 1e-3, 0.9, 0.999, 1e-7
+    for step in range(1, 6):
+        n = B if step != 4 else 13
+        rows = g.choice(N, n, replace=False).astype(np.int32)
+        eps = g.normal(size=(n, K)).astype(np.float32)
+        w0 = [x.astype(np.float64) for x in e.get_weights()]
+        m0 = [x.astype(np.float64) for x in e.get_moments(0)]
+        v0 = [x.astype(np.float64) for x in e.get_moments(1)]
+        c = O.forward(w0, dc[rows], eps.astype(np.float64), D, K)
+        gr = O.backward(w0, c, D, K)
+        loss, _, _ = e.train_step(rows, eps)
+        assert abs(loss - c["loss"]) <= RTOL * abs(c["loss"]), (step, loss, c["loss"])
+        alpha = lr * np.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        for i, (a, gi, mi) in enumerate(zip(e.get_moments(0), gr, m0)):
+            want = mi + (gi - mi) * (1 - b1)
+            assert np.abs(a - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-30), ("m", step, i, _relerr(a, want))
+        m1 = [x.astype(np.float64) for x in e.get_moments(0)]
+        v1 = [x.astype(np.float64) for x in e.get_moments(1)]
+        for i, (a, gi, vi) in enumerate(zip(v1, gr, v0)):
+            want = vi + (gi * gi - vi) * (1 - b2)
+            assert np.abs(a - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-30), ("v", step, i, _relerr(a, want))
+        for i, (a, b, mi, vi) in enumerate(zip(e.get_weights(), w0, m1, v1)):
+            want = -alpha * mi / (np.sqrt(vi) + eps_adam)   # from the engine's own new moments: the update arithmetic alone
+            err = np.abs((a.astype(np.float64) - b) - want).max()
+            assert err <= 1e-4 * lr + 1.2e-7 * max(1.0, np.abs(b).max()), ("w", step, i, err)
     e.close()
 
 
@@ -211,11 +253,11 @@ def test_large_batch_adam_steps_match_oracle(L, W, D, B):
         lg, _, _ = e.train_step(rows, eps)
         assert abs(lg - lo) <= RTOL * abs(lo), (step, lg, lo)
     for i, (a, b) in enumerate(zip(e.get_weights(), wo)):
-        assert np.abs(a.astype(np.float64) - b).max() <= 2e-2 * 5e-3, i
+        assert np.abs(a.astype(np.float64) - b).max() <= 4e-3 * 5e-3, i
     for i, (a, b) in enumerate(zip(e.get_moments(0), opt.m)):
-        assert _relerr(a, b) <= 1e-3, ("m", i, _relerr(a, b))
+        assert _relerr(a, b) <= 1e-4, ("m", i, _relerr(a, b))
     for i, (a, b) in enumerate(zip(e.get_moments(1), opt.v)):
-        assert _relerr(a, b) <= 1e-3, ("v", i, _relerr(a, b))
+        assert _relerr(a, b) <= 1e-4, ("v", i, _relerr(a, b))
     # 32-row steps still work on an engine made for larger batches (in-kernel Adam path)
     rows = g.choice(N, 20, replace=False).astype(np.int32)
     eps = g.normal(size=(20, K)).astype(np.float32)

@@ -190,6 +190,13 @@ int main() {
         vs.push_back({"oop interleaved chunk16 nt rr g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk_oop_il<16>), dim3(g), dim3(256), 0, 0, IL, IL2, n4 / (16 * 64)); }, 3, {}});
         vs.push_back({"oop interleaved chunk4 nt rr g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk_oop_il<4>), dim3(g), dim3(256), 0, 0, IL, IL2, n4 / (4 * 64)); }, 3, {}});
     }
+    for (int g : {512, 1024, 2048}) {
+        vs.push_back({"oop interleaved chunk1 nt rr g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk_oop_il<1>), dim3(g), dim3(256), 0, 0, IL, IL2, n4 / (1 * 64)); }, 3, {}});
+        vs.push_back({"oop interleaved chunk2 nt rr g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk_oop_il<2>), dim3(g), dim3(256), 0, 0, IL, IL2, n4 / (2 * 64)); }, 3, {}});
+    }
+    for (int g : {768, 1280, 1536}) {
+        vs.push_back({"copy 1.5GB->1.5GB nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_copy<1>), dim3(g), dim3(256), 0, 0, IL, IL2, 3 * n4); }, -1, {}});
+    }
     for (int g : {512, 768, 1024}) {
         vs.push_back({"inplace chunk16 contiguous g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk<3, 16, 0>), dim3(g), dim3(256), 0, 0, A, B, C, n4 / (16 * 64)); }, 3, {}});
         vs.push_back({"inplace chunk16 nt contiguous g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_chunk<3, 16, 1>), dim3(g), dim3(256), 0, 0, A, B, C, n4 / (16 * 64)); }, 3, {}});
