@@ -28,7 +28,12 @@
 #include "pvae_narrow.h"
 #include "pvae_pca.h"
 
-#define PV_VERSION "popvae_amd 0.2.0 (gfx950)"
+#define PV_VERSION "popvae_amd 0.3.0 (gfx950)"
+// passes over several row tiles: first-layer products on the bf16 matrix pipe at f32 accuracy (pvk_enc_fwd<.., BF = 1>);
+// -DPV_MT_BF16=0 builds the f32-pipe kernels instead (A/B)
+#ifndef PV_MT_BF16
+#define PV_MT_BF16 1
+#endif
 
 // pvae_train_step_noalloc: the split-K / split-N partial sums of the wide kernels (encpart, dgpart, losspart) live in this
 // file-scope device array instead of hipMalloc'ed buffers.  32 MiB per GPU the library runs on, held until the process
@@ -356,7 +361,9 @@ int setup_kernel_attrs(pvae_engine* e) {
     HIPCHK(allow_lds((pvk_enc_bwd<4, PV_MODE_GRAD, 0, TT>), TT * lds_enc_bwd(e->Wp)));                      \
     HIPCHK(allow_lds((pvk_enc_bwd<4, PV_MODE_TRAIN_ACC, 0, TT>), TT * lds_enc_bwd(e->Wp)));                 \
     HIPCHK(allow_lds((pvk_dec_eval_mt<TT, 0>), lds_dec_eval_mt(TT)));                                      \
-    HIPCHK(allow_lds((pvk_dec_eval_mt<TT, 1>), lds_dec_eval_mt(TT)));
+    HIPCHK(allow_lds((pvk_dec_eval_mt<TT, 1>), lds_dec_eval_mt(TT)));                                      \
+    HIPCHK(allow_lds((pvk_dec_eval_bf<TT, 0>), PvDecEvalBf<TT>::lds()));                                   \
+    HIPCHK(allow_lds((pvk_dec_eval_bf<TT, 1>), PvDecEvalBf<TT>::lds()));
     if (e->T == 2) {
         PV_ATTR_MT(2)
     } else if (e->T == 4) {
@@ -947,7 +954,7 @@ int multi_tile_launches(pvae_engine* e, int row_offset, float* d_out3, int mode)
                        e->dec3_wgs, e->dece_mt_wgs);
     {
         Timer t(e, C_ENC_FWD);
-        hipLaunchKernelGGL((pvk_enc_fwd<4, T>), dim3(e->encf_mt_wgs), dim3(256), kEncFwdLds, e->stream, e->W1.w, e->geno, e->row_bytes,
+        hipLaunchKernelGGL((pvk_enc_fwd<4, T, PV_MT_BF16>), dim3(e->encf_mt_wgs), dim3(256), kEncFwdLds, e->stream, e->W1.w, e->geno, e->row_bytes,
                            e->d_rows, e->st, row_offset, e->nblk, e->ngrp, e->encpart, e->ts4, (const uint64_t*)e->Xr);
         hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(nR)), dim3(256), 0, e->stream, e->encpart, e->encf_mt_wgs, nR, 0.5f,
                            e->P, (const float*)nullptr, (float*)nullptr);
@@ -1061,7 +1068,7 @@ int multi_tile_eval_launches(pvae_engine* e, int row_offset, int nrows, int n_ba
                        e->dec3_wgs, e->dece_mt_wgs);
     {
         Timer t(e, C_ENC_FWD);
-        hipLaunchKernelGGL((pvk_enc_fwd<4, T>), dim3(e->encf_mt_wgs), dim3(256), kEncFwdLds, e->stream, e->W1.w, e->geno, e->row_bytes,
+        hipLaunchKernelGGL((pvk_enc_fwd<4, T, PV_MT_BF16>), dim3(e->encf_mt_wgs), dim3(256), kEncFwdLds, e->stream, e->W1.w, e->geno, e->row_bytes,
                            e->d_rows, e->st, row_offset, e->nblk, e->ngrp, e->encpart, e->ts4, (const uint64_t*)e->Xr);
         hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(nR)), dim3(256), 0, e->stream, e->encpart, e->encf_mt_wgs, nR, 0.5f,
                            e->P, (const float*)nullptr, (float*)nullptr);
@@ -1074,6 +1081,11 @@ int multi_tile_eval_launches(pvae_engine* e, int row_offset, int nrows, int n_ba
     }
     if (nbatches > 0) {  // one loss per tile
         Timer t(e, C_DEC);
+        if (PV_MT_BF16)
+            hipLaunchKernelGGL((pvk_dec_eval_bf<T, 1>), dim3(e->dece_mt_wgs), dim3(512), PvDecEvalBf<T>::lds(), e->stream,
+                               (const float*)e->Vout.w, (const float*)e->cout.w, (const float*)e->g[e->D - 1], (const uint64_t*)e->Xt,
+                               e->nblk, (int)e->L, (const PvStep*)e->st, e->losspart, e->ts4);
+        else
         hipLaunchKernelGGL((pvk_dec_eval_mt<T, 1>), dim3(e->dece_mt_wgs), dim3(256), lds_dec_eval_mt(T), e->stream, (const float*)e->Vout.w,
                            (const float*)e->cout.w, (const float*)e->g[e->D - 1], (const uint64_t*)e->Xt, e->nblk, (int)e->L,
                            (const PvStep*)e->st, e->losspart, e->ts4);
@@ -1089,6 +1101,11 @@ int multi_tile_eval_launches(pvae_engine* e, int row_offset, int nrows, int n_ba
     }
     {
         Timer t(e, C_DEC);
+        if (PV_MT_BF16)
+            hipLaunchKernelGGL((pvk_dec_eval_bf<T, 0>), dim3(e->dece_mt_wgs), dim3(512), PvDecEvalBf<T>::lds(), e->stream,
+                               (const float*)e->Vout.w, (const float*)e->cout.w, (const float*)e->g[e->D - 1], (const uint64_t*)e->Xt,
+                               e->nblk, (int)e->L, (const PvStep*)e->st, e->losspart, e->ts4);
+        else
         hipLaunchKernelGGL((pvk_dec_eval_mt<T, 0>), dim3(e->dece_mt_wgs), dim3(256), lds_dec_eval_mt(T), e->stream, (const float*)e->Vout.w,
                            (const float*)e->cout.w, (const float*)e->g[e->D - 1], (const uint64_t*)e->Xt, e->nblk, (int)e->L,
                            (const PvStep*)e->st, e->losspart, e->ts4);
@@ -1455,7 +1472,9 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
         }
         // width 128: a workgroup's four waves are the block columns of one subtile slot
         if (e->T > 1) e->encf_mt_wgs = (int)balance(e->nblk, (int64_t)cus * 2);
-        if (e->T > 1) e->dece_mt_wgs = (int)((balance(e->nblk, (int64_t)cus * 2 * 4) + 3) / 4);
+        if (e->T > 1)  // f32 pipe: two 4-wave workgroups per CU; bf16 pipe: one 8-wave workgroup per CU (it shares the g table)
+            e->dece_mt_wgs = PV_MT_BF16 ? (int)((balance(e->nblk, (int64_t)cus * 8) + 7) / 8)
+                                        : (int)((balance(e->nblk, (int64_t)cus * 2 * 4) + 3) / 4);
         if (e->ngrp == 1) e->dec_wgs = (int)((balance(e->nblk, (int64_t)cus * o_dec * 4) + 3) / 4);
         else {  // a workgroup takes dec_grp_waves / ngrp SNP blocks per iteration
             const int bpi = dec_grp_waves(e->ngrp) / e->ngrp;
@@ -1886,7 +1905,7 @@ int pvae_encode(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps
             const int nR = B * e->Wp;
             if ((int64_t)e->encf_mt_wgs * nR > e->encpart_cap) return set_err(e, -6, "encode: partial-sum buffer smaller than the grid");
 #define PV_ENC_MT(TT)                                                                                                              \
-    hipLaunchKernelGGL((pvk_enc_fwd<4, TT>), dim3(e->encf_mt_wgs), dim3(256), kEncFwdLds, e->stream, e->W1.w, e->geno, e->row_bytes, \
+    hipLaunchKernelGGL((pvk_enc_fwd<4, TT, PV_MT_BF16>), dim3(e->encf_mt_wgs), dim3(256), kEncFwdLds, e->stream, e->W1.w, e->geno, e->row_bytes, \
                        e->d_rows, e->st, 0, e->nblk, e->ngrp, e->encpart, e->ts4, (const uint64_t*)nullptr)
             if (e->T == 2) PV_ENC_MT(2);
             else PV_ENC_MT(4);

@@ -258,13 +258,56 @@ __global__ __launch_bounds__(256) void pvk_gather_transpose(const uint8_t* __res
 // ---------------------------------------------------------------------------------------------
 // T = 32-row tiles of the device pass (1; 2 or 4 for a batch above 32 rows in ONE weight pass: the block is requested once
 // and multiplied with every tile's codes).  Rows of tile t are rows[row_offset + 32 t ..]; the partial tile is [32 T][Wp].
-template <int NWB, int T = 1>
+// BF = 1 (passes over several row tiles, which the f32 matrix pipe bounds: 4 tiles x 16 x 64 cycles per block against ~200 of
+// HBM time): the same products on the bf16 pipe at f32 accuracy.  Genotype codes {0, 1, 2} are exact in bf16; the weight is cut
+// into three bf16 terms, w = hi + mid + lo exactly (3 x 8 significand bits, by truncation: x & 0xFFFF0000, remainder, again),
+// every product code x term is exact and the accumulator is f32: 6 x v_mfma_f32_32x32x16_bf16 (32 cycles each) per block and
+// tile instead of 16 x v_mfma_f32_32x32x2_f32 (64 cycles each).  The contraction slots of the K = 16 instruction are filled in
+// the order the fragment-native tile already has: lane group h, element j of instruction i <-> SNP PV_ROW(8 i + j, h), for both
+// operands.  A operand: four bytes of the lane's genotype word (4 codes each) through a 256-entry table in LDS.
+typedef __bf16 pv_bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t pv_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t pv_u32x2 __attribute__((ext_vector_type(2)));
+// bf16 bit patterns of the four 2-bit codes in a byte (code 3 never occurs: pvae_load_genotypes rejects it)
+__device__ __forceinline__ pv_u32x2 pv_code_bf16_entry(int byte) {
+    auto f = [](int c) -> uint32_t { return c == 0 ? 0u : c == 1 ? 0x3F80u : 0x4000u; };
+    return pv_u32x2{f(byte & 3) | (f((byte >> 2) & 3) << 16), f((byte >> 4) & 3) | (f((byte >> 6) & 3) << 16)};
+}
+// high halves of two floats -> one register of two bf16 (truncation)
+__device__ __forceinline__ uint32_t pv_pack_hi16(float a, float b) {
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+// x[0..7] -> three bf16x8 operands whose sum is x exactly
+__device__ __forceinline__ void pv_split3(const float (&x)[8], pv_u32x4& hi, pv_u32x4& mid, pv_u32x4& lo) {
+    float r1[8], r2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        r1[i] = x[i] - __uint_as_float(__float_as_uint(x[i]) & 0xFFFF0000u);
+        r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xFFFF0000u);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = pv_pack_hi16(x[2 * i], x[2 * i + 1]);
+        mid[i] = pv_pack_hi16(r1[2 * i], r1[2 * i + 1]);
+        lo[i] = pv_pack_hi16(r2[2 * i], r2[2 * i + 1]);
+    }
+}
+__device__ __forceinline__ f32x16 pv_mfma_bf16(pv_u32x4 a, pv_u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pv_bf16x8, a), __builtin_bit_cast(pv_bf16x8, b), c, 0, 0, 0);
+}
+
+template <int NWB, int T = 1, int BF = 0>
 __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1, const uint8_t* __restrict__ geno,
                                                    int64_t row_bytes, const int* __restrict__ rows,
                                                    const PvStep* st, int row_offset, int nblk, int ngrp,
                                                    float* __restrict__ part, int ts, const uint64_t* __restrict__ Xr) {
     // Xr != NULL: the batch's words as pvk_gather_transpose left them (same values as the resident matrix's, compact)
     constexpr int WG_UNITS = NWB * 32;
+    __shared__ pv_u32x2 code_lut[BF ? 256 : 1];
+    if (BF) {
+        code_lut[threadIdx.x & 255] = pv_code_bf16_entry(threadIdx.x & 255);
+        __syncthreads();
+    }
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int grp = blockIdx.x % ngrp, gw = (blockIdx.x / ngrp) * 4 + wave;
     const int slot = gw / NWB, w = gw - slot * NWB;
@@ -284,13 +327,38 @@ __global__ __launch_bounds__(256) void pvk_enc_fwd(const float* __restrict__ W1,
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[t][0] += (float)(uint32_t)xw[t] + wv[0][0] + wv[1][1] + wv[2][2] + wv[3][3];
 #else
+        if constexpr (BF) {
+            pv_u32x4 bh[2], bm[2], bl[2];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const uint64_t xs = xw[t] >> (8 * h);
-            const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
+            for (int i = 0; i < 2; ++i) {
+                const float x[8] = {wv[2 * i][0], wv[2 * i][1], wv[2 * i][2], wv[2 * i][3],
+                                    wv[2 * i + 1][0], wv[2 * i + 1][1], wv[2 * i + 1][2], wv[2 * i + 1][3]};
+                pv_split3(x, bh[i], bm[i], bl[i]);
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv_code(lo, hi, r), wv[r >> 2][r & 3], acc[t], 0, 0, 0);
+            for (int t = 0; t < T; ++t) {
+                const uint64_t xs = xw[t] >> (8 * h);
+                const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
+                // codes r = 0..3 | 4..7 | 8..11 | 12..15 of pv_code: bytes 0 and 2 of the two halves
+                const pv_u32x2 c0 = code_lut[lo & 0xFF], c1 = code_lut[(lo >> 16) & 0xFF], c2 = code_lut[hi & 0xFF],
+                               c3 = code_lut[(hi >> 16) & 0xFF];
+                const pv_u32x4 a0 = {c0[0], c0[1], c1[0], c1[1]}, a1 = {c2[0], c2[1], c3[0], c3[1]};
+                acc[t] = pv_mfma_bf16(a0, bl[0], acc[t]);
+                acc[t] = pv_mfma_bf16(a1, bl[1], acc[t]);
+                acc[t] = pv_mfma_bf16(a0, bm[0], acc[t]);
+                acc[t] = pv_mfma_bf16(a1, bm[1], acc[t]);
+                acc[t] = pv_mfma_bf16(a0, bh[0], acc[t]);
+                acc[t] = pv_mfma_bf16(a1, bh[1], acc[t]);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const uint64_t xs = xw[t] >> (8 * h);
+                const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv_code(lo, hi, r), wv[r >> 2][r & 3], acc[t], 0, 0, 0);
+            }
         }
 #endif
     };
@@ -1228,15 +1296,22 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
                 cm = mC[l];
                 cv = vC[l];
             }
-            const f32x4* tM = reinterpret_cast<const f32x4*>(mV) + tb;
-            const f32x4* tVv = reinterpret_cast<const f32x4*>(vV) + tb;
+#ifndef PV_DEC2_VAR
+#define PV_DEC2_VAR 0
+#endif
             const f32x4* tVn = reinterpret_cast<const f32x4*>(V) + tile(nb);
+            if (PV_DEC2_VAR != 2) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) vn[q] = __builtin_nontemporal_load(tVn + q * 64);
+                for (int q = 0; q < 4; ++q) vn[q] = __builtin_nontemporal_load(tVn + q * 64);
+            }
+            if (PV_DEC2_VAR != 1) {
+                const f32x4* tM = reinterpret_cast<const f32x4*>(mV) + tb;
+                const f32x4* tVv = reinterpret_cast<const f32x4*>(vV) + tb;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                mq[q] = __builtin_nontemporal_load(tM + q * 64);
-                vq[q] = __builtin_nontemporal_load(tVv + q * 64);
+                for (int q = 0; q < 4; ++q) {
+                    mq[q] = __builtin_nontemporal_load(tM + q * 64);
+                    vq[q] = __builtin_nontemporal_load(tVv + q * 64);
+                }
             }
         }
         const uint64_t xs = xw >> (8 * h);
@@ -1269,11 +1344,25 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
             // mailboxes double as the V^T staging tiles of product (3): nobody overwrites one before all have read it
             sync_ok &= pv_block_sync(&blk_sync[bsub][1], NWB * nsync, lane);
         }
+        if (PV_DEC2_VAR == 1) {  // experiment: the moments requested behind product (1) instead of at the top of the visit
+            const f32x4* tM = reinterpret_cast<const f32x4*>(mV) + tb;
+            const f32x4* tVv = reinterpret_cast<const f32x4*>(vV) + tb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                mq[q] = __builtin_nontemporal_load(tM + q * 64);
+                vq[q] = __builtin_nontemporal_load(tVv + q * 64);
+            }
+        }
         // (2) sigmoid / BCE-from-logits / dlogits ; reg r <-> sample b = ROW(r,h), lane <-> SNP l (every wave of the block
         //     computes the same values)
         float dbias = 0.f;
         pv_sigmoid_bce(bce_probs, (blk * 32 + 32 <= L) && nrows >= 32, w == 0, a, bias, lo, hi, h, 0, nrows, lvalid, inv_b, lossacc,
                        dbias);
+        if (PV_DEC2_VAR == 2) {  // experiment: the next visit's V requested behind the sigmoid phase
+            const f32x4* tVn2 = reinterpret_cast<const f32x4*>(V) + tile(nb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vn[q] = __builtin_nontemporal_load(tVn2 + q * 64);
+        }
         // bias: sum over the 32 samples = 16 regs + the other half-wave; block column 0 updates it
         dbias += __shfl_xor(dbias, 32);
         if (w == 0 && h == 0 && lvalid) {
@@ -1780,6 +1869,118 @@ __global__ __launch_bounds__(256) void pvk_dec_eval_mt(const float* __restrict__
     }
     __syncthreads();
     if (tid < NL) losspart[tid * gridDim.x + blockIdx.x] = ((smem[tid * 4] + smem[tid * 4 + 1]) + smem[tid * 4 + 2]) + smem[tid * 4 + 3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same evaluation pass on the bf16 matrix pipe at f32 accuracy.  logits = g . V has two general operands: each is cut into
+// three bf16 terms (x = hi + mid + lo exactly, pv_split3) and the six products whose weight is at least 2^-16 of the result are
+// formed -- hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid; the three dropped ones are below 2^-24, the rounding of an f32 product
+// -- every one exact in the f32 accumulator's input: 12 x v_mfma_f32_32x32x16_bf16 (32 cycles each) per 32 x 32 x 32 block product
+// instead of 16 x v_mfma_f32_32x32x2_f32 (64 cycles each), 2.7 x less time on the matrix pipe, which bounds this pass (343 us
+// at 1M SNPs and four tiles against ~110 us of HBM time).  V is split in registers once per subtile (for all tiles); g is split
+// once per launch into an operand-order table in LDS (24 KB per tile: [tile][block column][instruction][term][lane] x 16 B, one
+// conflict-free ds_read_b128 per operand), shared by the EIGHT waves of a workgroup (one workgroup per CU).
+// ---------------------------------------------------------------------------------------------
+template <int T>
+struct PvDecEvalBf {
+    static constexpr int NW = 8;
+    static constexpr size_t lds() { return (size_t)T * 4 * 2 * 3 * 64 * 16; }
+};
+template <int T, int PER_TILE = 0>
+__global__ __launch_bounds__(512) void pvk_dec_eval_bf(const float* __restrict__ V, const float* __restrict__ cb,
+                                                       const float* __restrict__ g, const uint64_t* __restrict__ Xt, int nblk, int L,
+                                                       const PvStep* st, float* __restrict__ losspart, int ts) {
+    constexpr int NW = PvDecEvalBf<T>::NW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    pv_u32x4* gop = reinterpret_cast<pv_u32x4*>(smem);  // [T][4 w][2 i][3 term][64 lanes]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int gw = blockIdx.x * NW + wave, nwaves = gridDim.x * NW;
+    const int nrows = st->nrows;
+    const float inv_b = st->inv_b;
+    const int bce_probs = PV_BCE_MODE(st);
+    for (int e = tid; e < T * 4 * 2 * 64; e += NW * 64) {
+        const int ln = e & 63, i = (e >> 6) & 1, w = (e >> 7) & 3, t = e >> 9, cc = ln & 31, hh = ln >> 5;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = g[(32 * t + cc) * 128 + w * 32 + PV_ROW(8 * i + j, hh)];
+        pv_u32x4 th, tm, tl;
+        pv_split3(x, th, tm, tl);
+        pv_u32x4* dst = gop + (((t * 4 + w) * 2 + i) * 3) * 64 + ln;
+        dst[0] = th;
+        dst[64] = tm;
+        dst[128] = tl;
+    }
+    __syncthreads();
+    constexpr int NL = PER_TILE ? T : 1;
+    float lossacc[NL];
+#pragma unroll
+    for (int t = 0; t < NL; ++t) lossacc[t] = 0.f;
+    for (int blk = gw; blk < nblk; blk += nwaves) {
+        const f32x4* tV = reinterpret_cast<const f32x4*>(V) + (int64_t)blk * ts + lane;
+        pv_u32x4 bh[4][2], bm[4][2], bl[4][2];
+        {
+            f32x4 vv[4][4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vv[w][q] = __builtin_nontemporal_load(tV + (w * 4 + q) * 64);
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float x[8] = {vv[w][2 * i][0], vv[w][2 * i][1], vv[w][2 * i][2], vv[w][2 * i][3],
+                                        vv[w][2 * i + 1][0], vv[w][2 * i + 1][1], vv[w][2 * i + 1][2], vv[w][2 * i + 1][3]};
+                    pv_split3(x, bh[w][i], bm[w][i], bl[w][i]);
+                }
+        }
+        const int l = blk * 32 + c;
+        const bool lvalid = l < L;
+        const float bias = cb[lvalid ? l : L - 1];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (32 * t >= nrows) break;  // wave-uniform: tiles beyond the batch
+            const uint64_t xs = Xt[((int64_t)t * nblk + blk) * 32 + c] >> (8 * h);
+            const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
+            f32x16 a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const pv_u32x4* src = gop + (((t * 4 + w) * 2 + i) * 3) * 64 + lane;
+                    const pv_u32x4 ah = src[0], am = src[64], al = src[128];
+                    a = pv_mfma_bf16(al, bh[w][i], a);
+                    a = pv_mfma_bf16(ah, bl[w][i], a);
+                    a = pv_mfma_bf16(am, bm[w][i], a);
+                    a = pv_mfma_bf16(am, bh[w][i], a);
+                    a = pv_mfma_bf16(ah, bm[w][i], a);
+                    a = pv_mfma_bf16(ah, bh[w][i], a);
+                }
+            float dbias = 0.f;
+            pv_sigmoid_bce(bce_probs, (blk * 32 + 32 <= L) && (32 * t + 32 <= nrows), true, a, bias, lo, hi, h, 32 * t, nrows, lvalid,
+                           inv_b, lossacc[PER_TILE ? t : 0], dbias);
+        }
+    }
+    __syncthreads();
+    float* red = smem;
+#pragma unroll
+    for (int t = 0; t < NL; ++t) {
+        float v = lossacc[t];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane == 0) red[t * NW + wave] = v;
+    }
+    __syncthreads();
+    if (tid < NL) {
+        float sacc = 0.f;
+        for (int w2 = 0; w2 < NW; ++w2) sacc += red[tid * NW + w2];
+        losspart[tid * gridDim.x + blockIdx.x] = sacc;
+    }
 }
 
 // Loss scalars of up to T validation batches that went through one pass (pvk_dec_eval_mt<T, 1>): batch t = rows 32 t .. of the pass.

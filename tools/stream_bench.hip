@@ -153,6 +153,37 @@ __global__ __launch_bounds__(256) void k_copy4(const f32x4* a, f32x4* a2, size_t
     }
 }
 
+// D3: copy, each wave N KB contiguous per iteration (N loads, then N stores), chunks round-robin over the waves
+template <int N>
+__global__ __launch_bounds__(256) void k_copyN(const f32x4* a, f32x4* a2, size_t nchunks) {
+    const int lane = threadIdx.x & 63;
+    const size_t gw = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (size_t)gridDim.x * 4;
+    for (size_t ch = gw; ch < nchunks; ch += nw) {
+        f32x4 x[N];
+        const size_t o = ch * N * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < N; ++u) x[u] = __builtin_nontemporal_load(a + o + u * 64);
+#pragma unroll
+        for (int u = 0; u < N; ++u) __builtin_nontemporal_store(x[u], a2 + o + u * 64);
+    }
+}
+// D4: as D3 with N = 3, but the three loads of a wave are 1 KB pieces of three different thirds of a 3 N2-KB tile (the
+// W | m | v shape of the wide kernels: tile = [x N2 KB | y N2 KB | z N2 KB], wave w of the tile's N2 waves takes KB w of each)
+template <int N2>
+__global__ __launch_bounds__(256) void k_copy_tile(const f32x4* a, f32x4* a2, size_t ntiles) {
+    const int lane = threadIdx.x & 63;
+    const size_t gw = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (size_t)gridDim.x * 4;
+    for (size_t u = gw; u < ntiles * N2; u += nw) {
+        const size_t t = u / N2, w = u % N2;
+        const size_t o = (t * 3 * N2 + w) * 64 + lane;
+        const f32x4 x = __builtin_nontemporal_load(a + o), y = __builtin_nontemporal_load(a + o + N2 * 64),
+                    z = __builtin_nontemporal_load(a + o + 2 * N2 * 64);
+        __builtin_nontemporal_store(x, a2 + o);
+        __builtin_nontemporal_store(y, a2 + o + N2 * 64);
+        __builtin_nontemporal_store(z, a2 + o + 2 * N2 * 64);
+    }
+}
+
 template <typename F>
 float timeit(F f, int reps = 10) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -209,6 +240,15 @@ int main() {
         vs.push_back({"copy 1.5GB->1.5GB g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_copy<0>), dim3(g), dim3(256), 0, 0, IL, IL2, 3 * n4); }, -1, {}});
         vs.push_back({"copy 1.5GB->1.5GB nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_copy<1>), dim3(g), dim3(256), 0, 0, IL, IL2, 3 * n4); }, -1, {}});
         vs.push_back({"copy x4 1.5GB->1.5GB nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_copy4<1>), dim3(g), dim3(256), 0, 0, IL, IL2, 3 * n4); }, -1, {}});
+    }
+    for (int g : {512, 1024}) {
+        vs.push_back({"copyN N=1 nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_copyN<1>), dim3(g), dim3(256), 0, 0, IL, IL2, 3 * n4 / 64); }, -1, {}});
+        vs.push_back({"copyN N=2 nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_copyN<2>), dim3(g), dim3(256), 0, 0, IL, IL2, 3 * n4 / 128); }, -1, {}});
+        vs.push_back({"copyN N=3 nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_copyN<3>), dim3(g), dim3(256), 0, 0, IL, IL2, 3 * n4 / 192); }, -1, {}});
+        vs.push_back({"copyN N=4 nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_copyN<4>), dim3(g), dim3(256), 0, 0, IL, IL2, 3 * n4 / 256); }, -1, {}});
+        vs.push_back({"copyN N=12 nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_copyN<12>), dim3(g), dim3(256), 0, 0, IL, IL2, 3 * n4 / 768); }, -1, {}});
+        vs.push_back({"copy_tile 3x4KB nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_copy_tile<4>), dim3(g), dim3(256), 0, 0, IL, IL2, 3 * n4 / (12 * 64)); }, -1, {}});
+        vs.push_back({"copy_tile 3x16KB nt g" + std::to_string(g), [=] { hipLaunchKernelGGL((k_copy_tile<16>), dim3(g), dim3(256), 0, 0, IL, IL2, 3 * n4 / (48 * 64)); }, -1, {}});
     }
     vs.push_back({"hipMemcpyAsync D2D 1.5GB", [=] { hipMemcpyAsync(il2, il, 3 * n * 4, hipMemcpyDeviceToDevice, 0); }, -1, {}});
     for (int g : {512, 1024}) {
