@@ -31,7 +31,7 @@ typedef struct pvae_config {
     int32_t width;         /* --width  (popvae.py:78-80) */
     int32_t depth;         /* --depth  (popvae.py:75-77) */
     int32_t latent_dim;    /* --latent_dim (popvae.py:104-106) */
-    int32_t batch_size;    /* --batch_size (popvae.py:26); above 32 rows at width <= 128: one pass over the wide weights per 128 rows; otherwise 32-row tiles; gradients accumulated, one Adam update either way */
+    int32_t batch_size;    /* --batch_size (popvae.py:26); above 32 rows at a padded width of exactly 128 (widths 97..128): one pass over the wide weights per 128 rows; otherwise (widths <= 96, 256, 512) 32-row tiles; gradients accumulated, one Adam update either way */
     float lr, beta1, beta2, eps; /* Keras Adam defaults 1e-3, .9, .999, 1e-7 (popvae.py:426) */
     int32_t device_id;
     int32_t rank, world;   /* SNP-axis shard id / count */
@@ -82,8 +82,10 @@ int pvae_set_bce_mode(pvae_engine* e, int mode);
  * eps = injected N(0,1) [n][latent_dim] or NULL for the engine's own stream.
  * out3 = {loss, mean reconstruction, mean KL} or NULL (no host sync when NULL). */
 int pvae_train_step(pvae_engine* e, const int32_t* rows, int32_t n, const float* eps, float* out3);
-/* No counterpart in the reference: pvae_train_step for callers that cannot allocate (code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc).  Same arguments, same result bit for bit; the wide kernels'
+/* No counterpart in the reference: pvae_train_step for callers that cannot allocate (tight serving loops, harnesses that
+ * forbid hipMalloc; under HIP graph capture only with out3 == NULL and with rows / eps re-uploaded outside the graph: the call
+ * copies them into a pinned slot on the host at call time and, with out3 != NULL, synchronises the stream).  Same arguments,
+ * same result bit for bit; the wide kernels'
  * split-K / split-N partial sums live in a file-scope device array of the library (32 MiB per GPU, held until the
  * process ends) instead of hipMalloc'ed buffers, and the call performs no hipMalloc / hipHostMalloc / hipFree / event
  * creation.  Limits: 1 <= n <= 32 rows (one device pass), world == 1, event timing off, and the model's partial-sum
@@ -169,8 +171,11 @@ int pvae_comm_destroy(pvae_engine* e);
  * of all ranks to every rank (rank order, 64 bytes each), pvae_p2p_connect maps the peers' inboxes; from then on the ordinary
  * calls (pvae_train_epoch, pvae_train_step, pvae_encode, pvae_comm_allreduce ...) exchange through one kernel per exchange point
  * (pvk_p2p_allreduce: 8-byte {sequence, value} words written into every rank's inbox, summed in rank order).  Waits are bounded:
- * an exchange that gives up fills the buffer with NaN and pvae_p2p_status reports it.  At most 16 ranks.  Rehearsed with two
- * processes on one GPU (tests/test_gpu_dist.py); between devices it has not run yet. */
+ * an exchange that gives up (2^PVAE_P2P_SPIN_LOG2 polls of a word, default 2^26, about a minute) fills the buffer with NaN and
+ * raises the status word pvae_p2p_status reads -- the host checks it once per epoch and per encode, agrees on it across the
+ * ranks and ends the run (popvae_amd/dist.py check_exchange).  At most 16 ranks.  Before pvae_destroy frees an inbox every
+ * rank must have left its last exchange (the host barriers first).  Rehearsed with two processes on one GPU
+ * (tests/test_gpu_dist.py); between devices it has not run yet. */
 int pvae_p2p_prepare(pvae_engine* e, char* handle64);
 int pvae_p2p_connect(pvae_engine* e, const char* handles /* world x 64 bytes */);
 int pvae_p2p_status(pvae_engine* e, int32_t* gave_up);

@@ -72,11 +72,25 @@ def load_weights_file(path):
     top = root["model_weights"] if "model_weights" in root else root  # model.save(...) vs model.save_weights(...)
     if "layer_names" not in top.attrs:
         raise ValueError(f"{path}: no `layer_names` attribute -- not a Keras weight file")
-    out = []
-    for layer in _names(top.attrs["layer_names"]):
+    layers = _names(top.attrs["layer_names"])
+    # The reference attaches its loss with vae.add_loss() on symbolic tensors built from z_mean / z_log_var (popvae.py:416-424);
+    # Keras' functional add_loss may then list inner Dense / TFOpLambda / AddLoss layers in vae.layers besides the two nested
+    # models, so a file the reference wrote can hold extra top-level groups that repeat encoder kernels (UNPINNED: no Keras
+    # here to look).  When the nested models are there, they alone are read, in get_weights() order; otherwise every layer
+    # once, by weight name.
+    if "encoder" in layers and "decoder" in layers:
+        layers = ["encoder", "decoder"]
+    out, seen = [], set()
+    for layer in layers:
         grp = top[layer]
         for wn in _names(grp.attrs.get("weight_names", [])):
+            if wn in seen:
+                continue
+            seen.add(wn)
             out.append(np.array(grp[wn].data, dtype=np.float32))
+    if len(out) < 10 or (len(out) - 6) % 4:  # 2 tensors per Dense: depth + 2 encoder layers, depth + 1 decoder layers
+        raise ValueError(f"{path}: {len(out)} weight tensors; a popVAE model holds 4 * depth + 6 "
+                         f"(layers read: {', '.join(layers)})")
     return out
 
 

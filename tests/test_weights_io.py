@@ -90,3 +90,35 @@ def test_cross_check_against_libhdf5():
     p = subprocess.run([CONDA, "-W", "ignore", os.path.join(here, "tools", "check_h5lite.py")], capture_output=True, text=True,
                        env=env, timeout=120)
     assert p.returncode == 0 and "cross-check OK" in p.stdout, (p.stdout[-1000:], p.stderr[-2000:])
+
+
+def test_weight_file_with_extra_top_level_layers(tmp_path):
+    """A file the reference wrote may list more than [input, encoder, decoder] in `layer_names`: its loss is attached with
+    vae.add_loss() on tensors built from z_mean / z_log_var (popvae.py:416-424), and Keras' functional add_loss can add the inner
+    Dense layers and the op layers to vae.layers, whose groups then repeat encoder kernels (UNPINNED: no Keras here).  The
+    reader takes the nested models alone; a file whose tensor count is not 4 * depth + 6 is refused with a clear message."""
+    g = np.random.default_rng(3)
+    depth, L, W, K = 2, 50, 8, 2
+    shapes = [(L, W), (W,)] + [(W, W), (W,)] * (depth - 1) + [(W, K), (K,)] * 2 + [(K, W), (W,)] + [(W, W), (W,)] * (depth - 1) + [(W, L), (L,)]
+    w = [g.normal(size=s).astype(np.float32) for s in shapes]
+    p = weights_io.save_weights_hdf5(str(tmp_path / "w.hdf5"), w, depth)
+    root = h5lite.read(p)
+    mw = root["model_weights"]
+    enc, _ = weights_io.keras_weight_names(depth)
+    # the z_mean head once more as a top-level layer of its own, plus two weightless op layers
+    extra = mw.group("dense_2", attrs={"weight_names": np.array([enc[-4].encode(), enc[-3].encode()])})
+    extra.group("dense_2").dataset("kernel:0", w[2 * depth])
+    extra["dense_2"].dataset("bias:0", w[2 * depth + 1])
+    for name in ("tf.math.multiply", "add_loss"):
+        mw.group(name, attrs={"weight_names": np.array([], dtype="S1")})
+    mw.attrs["layer_names"] = np.array([b"input_1", b"encoder", b"dense_2", b"decoder", b"tf.math.multiply", b"add_loss"])
+    p2 = str(tmp_path / "w2.hdf5")   # (the tree read from `p` holds views of that file: write elsewhere)
+    h5lite.write(p2, root)
+    got = weights_io.load_weights_file(p2)
+    assert len(got) == len(w) and all(np.array_equal(a, b) for a, b in zip(got, w))
+    # without the nested models: every layer once, duplicates by weight name dropped, and the count is checked
+    mw.attrs["layer_names"] = np.array([b"input_1", b"encoder", b"dense_2"])
+    p3 = str(tmp_path / "w3.hdf5")
+    h5lite.write(p3, root)
+    with pytest.raises(ValueError, match="4 \\* depth \\+ 6"):
+        weights_io.load_weights_file(p3)
