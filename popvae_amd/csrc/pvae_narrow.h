@@ -23,7 +23,7 @@
 #include "pvae_kernels.h"
 
 #define PVQ_ROWS 4                 // batch rows per worker
-#define PVQ_THREADS 128            // two waves: wave h owns output columns [64 h, 64 h + 64)
+#define PVQ_THREADS 256            // four waves: 0 / 1 compute (wave h owns output columns [64 h, 64 h + 64)), 2 / 3 load kernels
 #define PVQ_WORKERS_PER_TILE 8     // workers per 32-row tile of a device pass
 #define PVQ_LDA (128 * PVQ_ROWS)   // floats of one activation buffer in LDS: [k < 128][row < 4]
 
@@ -79,8 +79,9 @@ __device__ __forceinline__ pvn_gf* pvn_g(float* p) { return (pvn_gf*)p; }
 __device__ __forceinline__ const pvn_gf4* pvn_g4(const float* p) { return (const pvn_gf4*)p; }
 
 #define PVN_MAXOPS 64
-__host__ __device__ inline size_t pvn_lds_fwd() { return (size_t)(2 * PVQ_LDA) * 4 + PVN_MAXOPS * sizeof(PvFwdOp); }
-__host__ __device__ inline size_t pvn_lds_bwd() { return (size_t)(2 * PVQ_LDA) * 4 + PVN_MAXOPS * sizeof(PvBwdOp); }
+// LDS of a worker: two activation buffers, the two-slot ring of layer kernels (64 KB each), the op table
+__host__ __device__ inline size_t pvn_lds_fwd() { return (size_t)(2 * PVQ_LDA + 2 * 128 * 128) * 4 + PVN_MAXOPS * sizeof(PvFwdOp); }
+__host__ __device__ inline size_t pvn_lds_bwd() { return (size_t)(2 * PVQ_LDA + 2 * 128 * 128) * 4 + PVN_MAXOPS * sizeof(PvBwdOp); }
 
 // The op table is cold in every launch (each step streams gigabytes through the caches in between), and a
 // scalar load that misses to HBM costs ~1-2 us per layer.  So the whole table is copied into LDS with one
@@ -132,74 +133,79 @@ __device__ unsigned long long pvn_trace_buf[2048];
 #define PVN_T(slot) do {} while (0)
 #endif
 
-// 128 B operands of a lane (its column of a layer's kernel) as SSA vectors (a float[128] passed by reference ends up in scratch)
-struct PvW128 {
-    f32x16 v[8];
-};
-#define PVQ_W(w, k) ((w).v[(k) >> 4][(k) & 15])
+// ---- loader / consumer split ------------------------------------------------------------------------------------------
+// A CU draws ~60-70 GB/s from its die's L2, so the 64 KB of a layer's kernel take ~1 us to arrive whatever the matrix pipe
+// does (MI355X_MICROARCH.md "Indexed rows": 66-73 GB/s per CU from L2; measured here: a chain whose waves loaded their own B
+// operands between their matrix instructions spent 1.1 us per layer in that phase with two register sets, and no less with
+// three).  What can be had is that NOTHING ELSE adds to it: waves 2 and 3 of a worker do nothing but move kernels from global
+// memory into a two-slot ring in LDS (op i + 1's while op i computes), waves 0 and 1 compute -- B operands by ds_read_b128
+// from the ring, one two-instruction-group ahead -- and the four meet at one barrier per op.
+#define PVQ_SLOT_FLOATS (128 * 128)  // one kernel copy: up to 64 chunks of 1 KB
 
-// chunk c (contraction steps 4c .. 4c + 3) of this wave's next B operands: 1 KB per wave instruction.  c is clamped to the
-// op's own chunk count, so that no load sits under a condition (a wave with nothing to prefetch passes nch = 1 and any valid
-// 1 KB); nbase / nch are wave-uniform (SGPRs): scalar address math.
-template <int C>
-__device__ __forceinline__ void pvq_load_chunk(PvW128& wn, const float* nbase, int nch, int lane) {
-    const f32x4 v = pvn_g4(nbase + 256 * min(C, nch - 1))[lane];
+// loader wave lw (0 / 1) copies chunks lw, lw + 2, ... of a copy of `N` chunks per loader: all loads first, then the LDS writes.
+// (Requesting op i + 2's kernel into registers an op ahead and writing it at the top of op i + 1 was built and measured slower,
+// 1.8 us per op against 1.3: the 32 ds_write_b128 of the two loaders -- 13 cycles each through the VGPR-to-LDS path -- then
+// land in one burst exactly where the consumers start reading their operands.)
+template <int N>
+__device__ __forceinline__ void pvq_fill(const float* __restrict__ src, float* slot, int lw, int lane) {
+    f32x4 v[N];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) wn.v[C >> 2][(4 * C + e) & 15] = v[e];
+    for (int i = 0; i < N; ++i) v[i] = pvn_g4(src + 256 * (2 * i + lw))[lane];
+#pragma unroll
+    for (int i = 0; i < N; ++i) reinterpret_cast<f32x4*>(slot)[(2 * i + lw) * 64 + lane] = v[i];
 }
-template <int C0, int C1>
-__device__ __forceinline__ void pvq_load_chunks(PvW128& wn, const float* nbase, int nch, int lane) {
-    if constexpr (C0 < C1) {
-        pvq_load_chunk<C0>(wn, nbase, nch, lane);
-        pvq_load_chunks<C0 + 1, C1>(wn, nbase, nch, lane);
+__device__ __forceinline__ void pvq_fill_op(const float* __restrict__ src, int nchunks, float* slot, int lw, int lane) {
+    switch (nchunks >> 1) {  // chunks per loader: 4, 8, 12, 16, 24 or 32 (contraction lengths and widths are multiples of 32)
+        case 4: pvq_fill<4>(src, slot, lw, lane); break;
+        case 8: pvq_fill<8>(src, slot, lw, lane); break;
+        case 12: pvq_fill<12>(src, slot, lw, lane); break;
+        case 16: pvq_fill<16>(src, slot, lw, lane); break;
+        case 24: pvq_fill<24>(src, slot, lw, lane); break;
+        default: pvq_fill<32>(src, slot, lw, lane); break;
     }
-}
-// the 32 chunks without a layer to hide behind (first op, ops without matrix instructions)
-__device__ __forceinline__ void pvq_prefetch_plain(PvW128& wn, const float* nbase, int nch, int lane) {
-    pvq_load_chunks<0, 32>(wn, nbase, nch, lane);
 }
 // 16 contraction steps: instruction b takes the A operand of block b (lanes 4b .. 4b + 3: rows 0..3 of step 16 j + b) for all
 // 64 columns (cbsz = 4, abid = b); four accumulators in rotation keep dependent instructions four apart
-template <int J, int B>
-__device__ __forceinline__ void pvq_mm16(f32x4 (&acc)[4], float a, const PvW128& w) {
+template <int B>
+__device__ __forceinline__ void pvq_mm16(f32x4 (&acc)[4], float a, const f32x4 (&w)[4]) {
     if constexpr (B < 16) {
-        acc[B & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, PVQ_W(w, 16 * J + B), acc[B & 3], 4, B, 0);
-        pvq_mm16<J, B + 1>(acc, a, w);
-    }
-}
-template <int KC16, int J>
-__device__ __forceinline__ void pvq_mma_groups(f32x4 (&acc)[4], const float (&a)[KC16], const PvW128& w, PvW128& wn,
-                                               const float* nbase, int nch, int lane) {
-    if constexpr (J < KC16) {
-        // this group's share of the next op's 32 chunks, issued ahead of its 16 matrix instructions: in one burst ahead of
-        // the whole layer the 64 loads of the two waves would queue at the CU's one address unit before the first instruction
-        pvq_load_chunks<J * 32 / KC16, (J + 1) * 32 / KC16>(wn, nbase, nch, lane);
-        pvq_mm16<J, 0>(acc, a[J], w);
-        __builtin_amdgcn_sched_barrier(0);
-        pvq_mma_groups<KC16, J + 1>(acc, a, w, wn, nbase, nch, lane);
+        acc[B & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, w[B >> 2][B & 3], acc[B & 3], 4, B, 0);
+        pvq_mm16<B + 1>(acc, a, w);
     }
 }
 // One layer's matrix instructions for this wave's 64 columns: a_lds = activation buffer + lane ([k][4 rows]: the operand of
-// steps 16 j .. 16 j + 15 is the word at 64 j + lane), KC16 = contraction length / 16.
+// steps 16 j .. 16 j + 15 is the word at 64 j + lane), w_lds = this wave's half of the ring slot + lane (chunk c at 64 c),
+// KC16 = contraction length / 16.
 template <int KC16>
-__device__ __forceinline__ f32x4 pvq_mma(const float* a_lds, const PvW128& w, PvW128& wn, const float* nbase, int nch, int lane) {
+__device__ __forceinline__ f32x4 pvq_mma(const float* a_lds, const f32x4* w_lds) {
     float a[KC16];
 #pragma unroll
     for (int j = 0; j < KC16; ++j) a[j] = a_lds[64 * j];
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // B operands two 16-step groups (eight ds_read_b128) ahead of the matrix instructions that use them, pinned by scheduling
+    // barriers: left alone the compiler keeps one read in flight and every four instructions wait for LDS (2300 cycles per
+    // layer against the 1100 the matrix pipe needs)
+    f32x4 w[3][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (g < KC16) w[g][q] = w_lds[(g * 4 + q) * 64];
     __builtin_amdgcn_sched_barrier(0);
-    pvq_mma_groups<KC16, 0>(acc, a, w, wn, nbase, nch, lane);
+#pragma unroll
+    for (int j = 0; j < KC16; ++j) {
+        if (j + 2 < KC16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[(j + 2) % 3][q] = w_lds[((j + 2) * 4 + q) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pvq_mm16<0>(acc, a[j], w[j % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
-// Wait-count discipline.  gfx9 has ONE counter for vector loads and stores, and with both kinds outstanding the compiler
-// has to wait for everything at the first use of a loaded register; __syncthreads() adds a full drain per layer on top
-// (its workgroup fence covers global memory).  Either would put ~1 us of store-acknowledge / load latency between
-// two layers.  So per op: the next op's operands are loaded DURING this op's matrix instructions, the counter is drained once
-// right AFTER them (the loads have had the whole phase, the previous op's stores a whole op), only then does the
-// epilogue issue this op's stores, and the barrier between ops orders LDS only.
-#define PVN_DRAIN_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70) /* vmcnt(0), expcnt / lgkmcnt untouched */
 __device__ __forceinline__ void pvn_lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
@@ -227,9 +233,12 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cur = smem;                   // [k][PVQ_ROWS]
     float* nxt = smem + PVQ_LDA;
-    int* ops_s = reinterpret_cast<int*>(smem + 2 * PVQ_LDA);
+    float* ring = smem + 2 * PVQ_LDA;    // two slots of PVQ_SLOT_FLOATS
+    int* ops_s = reinterpret_cast<int*>(ring + 2 * PVQ_SLOT_FLOATS);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int n = wave * 64 + lane;             // this lane's output column
+    const bool loader = wave >= 2;
+    const int h = wave & 1;                     // consumer: which 64 output columns; loader: which chunks
+    const int n = h * 64 + lane;                // (consumer) this lane's output column
     const int rb = PVQ_ROWS * (int)blockIdx.x;  // first batch row of this worker
     if ((int)blockIdx.x >= nworkers) {
         const int p = ((int)blockIdx.x - nworkers) >> 3;
@@ -241,44 +250,28 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
     }
     pvn_stage_ops(ops, nops, ops_s, tid);
     __syncthreads();
-
-    // where this wave's B operands of op `o` start; a wave that has nothing to load for `o` gets a harmless address
-    const float* nbase = P;
-    int nch = 1;
-    auto aim = [&](const PvFwdOp& o) {
-        nbase = P; nch = 1;
-        if (o.kind != PVN_DENSE || wave * 64 >= o.nout) return;
-        nch = o.kin >> 2;
-        nbase = o.W + wave * nch * 256;
-    };
     if (op0 > 0) {  // decoder.predict: start behind REPARAM with z (already in z_out) as the activation
         for (int i = tid; i < PVQ_ROWS * Kz; i += PVQ_THREADS) cur[i] = z_out[(rb + (i & 3)) * Kz + (i >> 2)];
-        __syncthreads();
     }
     PvFwdOp op = pvn_get_op<PvFwdOp>(ops_s, op0);
-    PvW128 wnext;
-    aim(op);
-    pvq_prefetch_plain(wnext, nbase, nch, lane);
-    PVN_DRAIN_VMEM();
-    // One op: wcur = its B operands (loaded during the previous op), wnext = where the next op's go.  The loop below calls
-    // it twice per iteration with the two register sets swapped: copying one set into the other between ops (128 moves per
-    // lane and op) was a tenth of the chain's time.
-    auto step = [&](const PvW128& wcur, PvW128& wnext, const int i) __attribute__((always_inline)) {
-        PVN_T(i * 8 + 0);
-        const int N = op.nout;
-        // this op's bias: issued here, complete at the drain behind the matrix instructions (op.b is never null)
-        const float bcur = pvn_g(op.b)[n < N ? n : 0];
+    auto chunks = [](const PvFwdOp& o) { return (int)(pvn_wf_floats(o.kin, o.nout) >> 8); };
+    if (loader && op.kind == PVN_DENSE) pvq_fill_op(op.W, chunks(op), ring, h, lane);
+    pvn_lds_barrier();
+    for (int i = op0; i < nops; ++i) {
         const PvFwdOp nx = i + 1 < nops ? pvn_get_op<PvFwdOp>(ops_s, i + 1) : op;
-        if (i + 1 < nops) aim(nx);
-        else { nbase = P; nch = 1; }
-        PVN_T(i * 8 + 1);
-        if (op.kind == PVN_REPARAM) {
-            pvq_prefetch_plain(wnext, nbase, nch, lane);
-            PVN_DRAIN_VMEM();
+        const float* wslot = ring + ((i - op0) & 1) * PVQ_SLOT_FLOATS;
+        float* nslot = ring + ((i - op0 + 1) & 1) * PVQ_SLOT_FLOATS;
+        const int N = op.nout;
+        if (loader) {
+            // op i + 1's kernel into the other slot (free since the barrier behind op i - 1)
+            if (i + 1 < nops && nx.kind == PVN_DENSE) pvq_fill_op(nx.W, chunks(nx), nslot, h, lane);
+            if (op.kind == PVN_REPARAM) pvn_lds_barrier();  // the consumers' sync point inside that op
+        } else if (op.kind == PVN_REPARAM) {
+            PVN_T(i * 8 + 0);
             // cur holds the heads output: k in [0,K) = z_mean, [K,2K) = z_log_var; nxt gets z (padded to Kz).  One (k, row)
             // pair per thread; the KL terms meet in LDS and are summed per row in k order.
             float* klt = nxt + Kz * PVQ_ROWS;  // [K][rows], behind z: the next op (contraction length Kz) never reads it
-            for (int i2 = tid; i2 < PVQ_ROWS * Kz; i2 += PVQ_THREADS) {
+            for (int i2 = tid; i2 < PVQ_ROWS * Kz; i2 += 128) {
                 const int k = i2 >> 2, r = i2 & 3, b = rb + r;
                 float zz = 0.f;
                 if (k < K) {
@@ -296,18 +289,19 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
                 for (int k = 0; k < K; ++k) acc += klt[k * PVQ_ROWS + tid];
                 kl_out[rb + tid] = -0.5f * acc;
             }
-        } else if (wave * 64 < N) {
+        } else if (h * 64 < N) {
+            PVN_T(i * 8 + 0);
+            // this op's bias: issued here, complete when the epilogue needs it (op.b is never null)
+            const float bcur = pvn_g(op.b)[n < N ? n : 0];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             if (op.kind == PVN_BIAS_ACT) {
                 if (n < N) {
 #pragma unroll
                     for (int r = 0; r < PVQ_ROWS; ++r) acc[r] = P[(rb + r) * N + n];
                 }
-                pvq_prefetch_plain(wnext, nbase, nch, lane);
-            PVN_DRAIN_VMEM();
             } else {
-                PVQ_SWITCH(op.kin, (acc = pvq_mma<C_>(cur + lane, wcur, wnext, nbase, nch, lane)));
-                PVN_DRAIN_VMEM();
+                const f32x4* w_lds = reinterpret_cast<const f32x4*>(wslot) + h * (op.kin >> 2) * 64 + lane;
+                PVQ_SWITCH(op.kin, (acc = pvq_mma<C_>(cur + lane, w_lds)));
             }
 #ifdef PVN_TRACE
             asm volatile("s_nop 0" ::"v"(acc));
@@ -324,22 +318,14 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
 #pragma unroll
                 for (int r = 0; r < PVQ_ROWS; ++r) pvn_g(op.out)[(rb + r) * N + n] = y[r];
             }
-        } else {
-            pvq_prefetch_plain(wnext, nbase, nch, lane);
-            PVN_DRAIN_VMEM();
+            PVN_T(i * 8 + 3);
         }
-        PVN_T(i * 8 + 3);
-        pvn_lds_barrier();  // nxt complete, every read of cur done
-        PVN_T(i * 8 + 4);
+        pvn_lds_barrier();  // nxt complete, every read of cur and of this op's slot done, the next op's slot filled
+        if (!loader) PVN_T(i * 8 + 4);
         float* t_ = cur;
         cur = nxt;
         nxt = t_;
         op = nx;
-    };
-    PvW128 wother;
-    for (int i = op0; i < nops; i += 2) {
-        step(wnext, wother, i);
-        if (i + 1 < nops) step(wother, wnext, i + 1);
     }
 }
 
@@ -348,8 +334,8 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
 //   dpre = dY * act'(Y)  (saved to global for part 2),  dIn = dpre * W^T  -> dY of the next op.
 // Ops: decoder layers D..1, REPARAM (dz -> dmu, ds), heads, encoder layers D..2, FIRST_BIAS (dpre1 + b1 Adam).
 // dY of the first op = xch[0 .. rows*W0): the all-reduced decoder feedback; xch[rows*W0] = summed BCE.
-// Same structure as the forward: lane l of wave h owns column 64 h + l of dIn for the worker's four rows, and the epilogue of
-// op i turns it straight into the NEXT op's dpre (times act'(Y), rows beyond the batch zeroed), in LDS for the
+// Same structure as the forward: lane l of consumer wave h owns column 64 h + l of dIn for the worker's four rows, and the
+// epilogue of op i turns it straight into the NEXT op's dpre (times act'(Y), rows beyond the batch zeroed), in LDS for the
 // chain and in global memory for part 2.  The weights are only READ here; part 2 (pvk_narrow_adam, one wave per
 // 32x32 weight block, spread over the chip) forms dW = in^T * dpre and applies Adam.
 // ---------------------------------------------------------------------------------------------
@@ -364,9 +350,12 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cur = smem;
     float* nxt = smem + PVQ_LDA;
-    int* ops_s = reinterpret_cast<int*>(smem + 2 * PVQ_LDA);
+    float* ring = smem + 2 * PVQ_LDA;
+    int* ops_s = reinterpret_cast<int*>(ring + 2 * PVQ_SLOT_FLOATS);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int n = wave * 64 + lane;
+    const bool loader = wave >= 2;
+    const int h = wave & 1;
+    const int n = h * 64 + lane;
     const int rb = PVQ_ROWS * (int)blockIdx.x;  // first batch row of this worker
     if ((int)blockIdx.x >= nworkers) {
         const int p = ((int)blockIdx.x - nworkers) >> 3;
@@ -391,51 +380,42 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     if (!update) return;
     __syncthreads();
 
-    // B operands of op o: lane l of wave h needs row 64 h + l of W (input unit k), all nout entries of it
-    const float* nbase = xch;
-    int nch = 1;
-    auto aim = [&](const PvBwdOp& o) {
-        nbase = xch; nch = 1;
-        if (o.kind != PVN_DENSE || wave * 64 >= o.kin) return;
-        nch = o.nout >> 2;
-        nbase = o.Wb + wave * nch * 256;
-    };
     PvBwdOp op = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, 0);
-    PvW128 wnext;
-    aim(op);
-    pvq_prefetch_plain(wnext, nbase, nch, lane);
-    {   // dpre of the first op from the exchanged decoder feedback
-        if (n < W0) {
-            float xv[PVQ_ROWS], yv[PVQ_ROWS];
+    auto chunks = [](const PvBwdOp& o) { return (int)(pvn_wb_floats(o.kin, o.nout) >> 8); };
+    if (loader) {
+        if (op.kind == PVN_DENSE) pvq_fill_op(op.Wb, chunks(op), ring, h, lane);
+    } else if (n < W0) {  // dpre of the first op from the exchanged decoder feedback
+        float xv[PVQ_ROWS], yv[PVQ_ROWS];
 #pragma unroll
-            for (int r = 0; r < PVQ_ROWS; ++r) {
-                xv[r] = xch[(rb + r) * W0 + n];
-                yv[r] = pvn_g(op.Y)[(rb + r) * W0 + n];
-            }
-            f32x4 dv;
-#pragma unroll
-            for (int r = 0; r < PVQ_ROWS; ++r) {
-                float d = rb + r < nrows ? xv[r] : 0.f;
-                if (op.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[r]);
-                dv[r] = d;
-                pvn_g(op.dpre)[(rb + r) * W0 + n] = d;
-            }
-            *reinterpret_cast<f32x4*>(cur + PVQ_ROWS * n) = dv;
+        for (int r = 0; r < PVQ_ROWS; ++r) {
+            xv[r] = xch[(rb + r) * W0 + n];
+            yv[r] = pvn_g(op.Y)[(rb + r) * W0 + n];
         }
+        f32x4 dv;
+#pragma unroll
+        for (int r = 0; r < PVQ_ROWS; ++r) {
+            float d = rb + r < nrows ? xv[r] : 0.f;
+            if (op.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[r]);
+            dv[r] = d;
+            pvn_g(op.dpre)[(rb + r) * W0 + n] = d;
+        }
+        *reinterpret_cast<f32x4*>(cur + PVQ_ROWS * n) = dv;
     }
-    PVN_DRAIN_VMEM();
     pvn_lds_barrier();
 
-    // (two register sets in alternation, as in the forward)
-    auto step = [&](const PvW128& wb, PvW128& wnext, const int i) __attribute__((always_inline)) {
-        PVN_T(128 + i * 8 + 0);
+    // dpre1 is in global memory once the op before FIRST_BIAS has run (its epilogue), for the wide encoder backward and
+    // for pvk_narrow_adam, which also sums it over the batch for b1 (the rows are spread over the workers here)
+    for (int i = 0; i < nops; ++i) {
+        if (op.kind == PVN_FIRST_BIAS) break;
         const PvBwdOp nx = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, i + 1);  // the table always ends with FIRST_BIAS
-        aim(nx);
-        if (op.kind == PVN_REPARAM) {
-            pvq_prefetch_plain(wnext, nbase, nch, lane);
-            PVN_DRAIN_VMEM();
+        const float* wslot = ring + (i & 1) * PVQ_SLOT_FLOATS;
+        float* nslot = ring + ((i + 1) & 1) * PVQ_SLOT_FLOATS;
+        if (loader) {
+            if (nx.kind == PVN_DENSE) pvq_fill_op(nx.Wb, chunks(nx), nslot, h, lane);
+        } else if (op.kind == PVN_REPARAM) {
+            PVN_T(128 + i * 8 + 0);
             // cur = dz [Kz][rows]; result: dpre of the heads op [Kh][rows] (k in [0,K) dmu, [K,2K) ds, rest 0)
-            for (int i2 = tid; i2 < PVQ_ROWS * Kh; i2 += PVQ_THREADS) {  // one (k, row) pair per thread
+            for (int i2 = tid; i2 < PVQ_ROWS * Kh; i2 += 128) {  // one (k, row) pair per thread
                 const int k = i2 >> 2, r = i2 & 3, b = rb + r;
                 if (k >= 2 * K) {
                     nxt[i2] = 0.f;
@@ -454,7 +434,8 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                     pvn_g(nx.dpre)[b * Kh + K + k] = dsv;
                 }
             }
-        } else if (wave * 64 < op.kin) {
+        } else if (h * 64 < op.kin) {
+            PVN_T(128 + i * 8 + 0);
             const int Kin = op.kin;
             const bool to_dpre = nx.kind != PVN_REPARAM;  // REPARAM consumes the raw dz
             const bool mine = n < Kin;
@@ -465,13 +446,13 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
             }
             f32x4 acc;
             PVN_T(128 + i * 8 + 1);
-            PVQ_SWITCH(op.nout, (acc = pvq_mma<C_>(cur + lane, wb, wnext, nbase, nch, lane)));
+            const f32x4* w_lds = reinterpret_cast<const f32x4*>(wslot) + h * (op.nout >> 2) * 64 + lane;
+            PVQ_SWITCH(op.nout, (acc = pvq_mma<C_>(cur + lane, w_lds)));
 #ifdef PVN_TRACE
             asm volatile("s_nop 0" ::"v"(acc));
             PVN_T(128 + i * 8 + 5);
-#endif
-            PVN_DRAIN_VMEM();
             PVN_T(128 + i * 8 + 2);
+#endif
             if (mine) {
                 f32x4 dv;
 #pragma unroll
@@ -486,26 +467,14 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                 }
                 *reinterpret_cast<f32x4*>(nxt + PVQ_ROWS * n) = dv;
             }
-        } else {
-            pvq_prefetch_plain(wnext, nbase, nch, lane);
-            PVN_DRAIN_VMEM();
+            PVN_T(128 + i * 8 + 3);
         }
-        PVN_T(128 + i * 8 + 3);
         pvn_lds_barrier();
-        PVN_T(128 + i * 8 + 4);
+        if (!loader) PVN_T(128 + i * 8 + 4);
         float* t_ = cur;
         cur = nxt;
         nxt = t_;
         op = nx;
-    };
-    // dpre1 is in global memory once the op before FIRST_BIAS has run (its epilogue), for the wide encoder backward and
-    // for pvk_narrow_adam, which also sums it over the batch for b1 (the rows are spread over the workers here)
-    PvW128 wother;
-    for (int i = 0; i < nops; i += 2) {
-        if (op.kind == PVN_FIRST_BIAS) break;
-        step(wnext, wother, i);
-        if (op.kind == PVN_FIRST_BIAS) break;
-        step(wother, wnext, i + 1);
     }
 }
 
