@@ -69,8 +69,8 @@ struct TensorRef {
     int64_t rows, cols;  // Keras shape (cols = 0 for bias)
 };
 
-enum Cat { C_GATHER, C_ENC_FWD, C_NARROW_FWD, C_DEC, C_NARROW_BWD, C_ENC_BWD, C_XCH0, C_XCH1, C_NCAT };
-const char* kCatNames[C_NCAT] = {"gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd", "xch0", "xch1"};
+enum Cat { C_GATHER, C_ENC_FWD, C_NARROW_FWD, C_DEC, C_NARROW_BWD, C_ENC_BWD, C_XCH0, C_XCH1, C_DEC_UPD, C_NCAT };
+const char* kCatNames[C_NCAT] = {"gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd", "xch0", "xch1", "dec_upd"};
 
 }  // namespace
 
@@ -79,6 +79,14 @@ struct pvae_engine {
     std::string err;
     int dev = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // The decoder pass in two launches (SNP shards and other short SNP axes; pvk_dec2<.., PART>): the loss + dg launch stays on
+    // `stream` and feeds the backward chain, the dV + Adam launch goes to `side`, a stream whose CU mask leaves a few CUs of
+    // every XCD free for the chain (its workgroups need 135 KB of LDS: they fit on no CU that holds a decoder workgroup).
+    hipStream_t side = nullptr;
+    hipEvent_t ev_da = nullptr, ev_upd = nullptr;
+    bool split_dec = false;    // configured at pvae_create
+    bool split_now = false;    // the epoch loop is in its plain one-tile training steps
+    bool upd_pending = false;  // a dV + Adam launch is in flight on `side`: `stream` has not waited for it yet
     // dims
     int64_t L = 0, Lp = 0;
     int nblk = 0, W = 0, Wp = 0, NWB = 0, ngrp = 0, D = 0, K = 0, Kh = 0, Kz = 0;
@@ -286,7 +294,8 @@ struct Timer {
     pvae_engine* e;
     bool on;
     size_t idx = 0;
-    Timer(pvae_engine* e_, int cat) : e(e_), on(e_->timing && ((e_->timing_mask >> cat) & 1u)) {
+    hipStream_t s;
+    Timer(pvae_engine* e_, int cat, hipStream_t s_ = nullptr) : e(e_), on(e_->timing && ((e_->timing_mask >> cat) & 1u)), s(s_ ? s_ : e_->stream) {
         if (!on) return;
         if (e->ev_used == e->evs.size()) {
             pvae_engine::Ev ev;
@@ -296,16 +305,17 @@ struct Timer {
         }
         idx = e->ev_used++;
         e->evs[idx].cat = cat;
-        hipEventRecord(e->evs[idx].a, e->stream);
+        hipEventRecord(e->evs[idx].a, s);
     }
     ~Timer() {
-        if (on) hipEventRecord(e->evs[idx].b, e->stream);
+        if (on) hipEventRecord(e->evs[idx].b, s);
     }
 };
 
 void flush_timing(pvae_engine* e) {
     if (!e->ev_used) return;
     hipStreamSynchronize(e->stream);
+    if (e->side) hipStreamSynchronize(e->side);
     for (size_t i = 0; i < e->ev_used; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e->evs[i].a, e->evs[i].b) == hipSuccess) {
@@ -345,6 +355,8 @@ int setup_kernel_attrs(pvae_engine* e) {
     HIPCHK(allow_lds(pvk_narrow_bwd<PV_MODE_TRAIN_ACC>, pvn_lds_bwd()));
 #define PV_ATTR(N)                                                                    \
     HIPCHK(allow_lds(pvk_dec2<N>, PvDec2<N>::lds()));                                 \
+    HIPCHK(allow_lds(pvk_dec2<N, 1>, PvDec2<N>::lds()));                              \
+    HIPCHK(allow_lds(pvk_dec2<N, 2>, PvDec2<N>::lds()));                              \
     HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_TRAIN>, lds_dec(N)));                      \
     HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_GRAD>, lds_dec(N)));                       \
     HIPCHK(allow_lds(pvk_dec<N, 1, PV_MODE_TRAIN_ACC>, lds_dec(N)));                  \
@@ -643,6 +655,20 @@ int narrow_decoder(pvae_engine* e) {
     return 0;
 }
 
+// `stream` waits for the decoder update in flight on `side` (everything that reads or writes V | m | v, the output bias, the
+// step scalars, the batch words or the last decoder activation comes behind it)
+int join_side(pvae_engine* e) {
+    if (!e->upd_pending) return 0;
+    e->upd_pending = false;
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_upd, 0));
+    return 0;
+}
+struct SplitScope {  // the epoch loop's plain training steps; leaves with the side stream joined, whatever the exit
+    pvae_engine* e;
+    explicit SplitScope(pvae_engine* e_, bool on) : e(e_) { e->split_now = on; }
+    ~SplitScope() { e->split_now = false; join_side(e); }
+};
+
 // stage B: narrow forward + fused wide decoder -> xch1 (dg partial sums over this rank's SNPs, recon sums)
 int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
     int rc;
@@ -690,7 +716,21 @@ int stage_b(pvae_engine* e, int mode /*0 train,1 eval,2 grad*/) {
 #undef PV_K3
         } else {
 #define PV_K3(TR, MD) pvk_dec<N_, TR, MD>
-            if (mode == 0 && e->dec2_wgs) {  // plain training pass: block-column split
+            if (mode == 0 && e->dec2_wgs && e->split_now) {  // the pass in two launches, the second beside the backward chain
+                PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec2<N_, 1>), dim3(e->dec2_wgs), dim3(PvDec2<N_>::NW * 64), PvDec2<N_>::lds(),
+                                                      e->stream, aV, amV, avV, aV2, amV2, avV2, acb, amC, avC, gD, e->xt_act, e->nblk,
+                                                      (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4));
+                HIPCHK(hipEventRecord(e->ev_da, e->stream));
+                HIPCHK(hipStreamWaitEvent(e->side, e->ev_da, 0));
+                {
+                    Timer t2(e, C_DEC_UPD, e->side);
+                    PV_DISPATCH_NWB(e, hipLaunchKernelGGL((pvk_dec2<N_, 2>), dim3(e->dec2_wgs), dim3(PvDec2<N_>::NW * 64), PvDec2<N_>::lds(),
+                                                          e->side, aV, amV, avV, aV2, amV2, avV2, acb, amC, avC, gD, e->xt_act, e->nblk,
+                                                          (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4));
+                }
+                HIPCHK(hipEventRecord(e->ev_upd, e->side));
+                e->upd_pending = true;
+            } else if (mode == 0 && e->dec2_wgs) {  // plain training pass: block-column split
                 PV_DISPATCH_NWB(e, hipLaunchKernelGGL(pvk_dec2<N_>, dim3(e->dec2_wgs), dim3(PvDec2<N_>::NW * 64), PvDec2<N_>::lds(),
                                                       e->stream, aV, amV, avV, aV2, amV2, avV2, acb, amC, avC, gD, e->xt_act, e->nblk,
                                                       (int)e->L, e->st, e->adam, e->dgpart, e->losspart, e->ts4));
@@ -1536,6 +1576,28 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     CK(scratch_address(e, e->dev, &e->scratch));
     e->fused_narrow = e->Wp <= 128 && 2 * e->D + 2 <= PVN_MAXOPS && !getenv("PVAE_NO_FUSED_NARROW");
     e->narrow_warm = !getenv("PVAE_NO_NARROW_WARM");
+    {
+        const char* sd = getenv("PVAE_SPLIT_DEC");
+        e->split_dec = e->dec2_wgs && e->fused_narrow && sd && atoi(sd) > 0;
+        if (e->split_dec) {
+            // CU mask of the side stream: R CUs of every XCD stay free.  Bit i of the mask is a CU of XCD i % 8 under the
+            // driver's interleaved numbering and of XCD i / 32 under a contiguous one; clearing in word w the bits b with
+            // b % 8 == w % 8 (b / 8 < R) reserves R CUs per XCD either way.
+            hipDeviceProp_t pr;
+            HK(hipGetDeviceProperties(&pr, e->dev));
+            const int cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256, words = (cus + 31) / 32;
+            const char* rv = getenv("PVAE_SPLIT_RESERVE");
+            const int R = rv ? std::max(0, std::min(4, atoi(rv))) : 4;
+            std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
+            for (int w = 0; w < words; ++w)
+                for (int b = 0; b < 32; ++b)
+                    if (b % 8 == w % 8 && b / 8 < R) mask[w] &= ~(1u << b);
+            if (cus % 32) mask[words - 1] &= (1u << (cus % 32)) - 1;
+            HK(hipExtStreamCreateWithCUMask(&e->side, (uint32_t)words, mask.data()));
+            HK(hipEventCreateWithFlags(&e->ev_da, hipEventDisableTiming));
+            HK(hipEventCreateWithFlags(&e->ev_upd, hipEventDisableTiming));
+        }
+    }
     CK(build_bwd_ops(e, false, &e->d_bwd_ops));  // also allocates the operand-order copies the forward table points to
     if (e->fused_narrow) CK(build_fwd_ops(e));
     HK(hipStreamSynchronize(e->stream));
@@ -1550,6 +1612,9 @@ int pvae_destroy(pvae_engine* e) {
     if (!e) return 0;
     hipSetDevice(e->dev);
     if (e->own_stream) hipStreamSynchronize(e->own_stream);
+    if (e->side) { hipStreamSynchronize(e->side); hipStreamDestroy(e->side); }
+    if (e->ev_da) hipEventDestroy(e->ev_da);
+    if (e->ev_upd) hipEventDestroy(e->ev_upd);
     pvae_comm_destroy(e);
     if (e->p2p_inbox) hipFree(e->p2p_inbox);
     if (e->p2p_status) hipFree(e->p2p_status);
@@ -1806,7 +1871,9 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
         HIPCHK(hipMemcpyAsync(e->d_ntotal, &nt, sizeof(int), hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));  // nt is a stack variable
         const int base = phase == 0 ? 0 : n_train;
+        SplitScope split(e, phase == 0 && e->split_dec);
         for (int s = 0; s < steps; ++s) {
+            if ((rc = join_side(e))) return rc;
             // the first-layer forward of the NEXT batch rides on this step's wide encoder backward
             int next_off = 0, next_n = 0;
             bool fuse = false;

@@ -1222,7 +1222,13 @@ struct PvDec2 {
     static constexpr int WP = NWB * 32, LDG = WP + 1;
     static constexpr size_t lds() { return (size_t)(32 * LDG + NW * 2 * 32 * 33) * 4; }
 };
-template <int NWB>
+// PART: 0 = the whole pass.  The pass in two launches (SNP shards, where the serial narrow chain is a third of the step):
+//   1 = loss + dg only: products (1)-(3), reads V, the batch words and the bias -- 4 bytes per parameter; its dg partial
+//       tiles feed the backward chain at once;
+//   2 = dV + Adam only: products (1), (2), (4), the full read and write of V | m | v; it needs nothing the backward chain
+//       produces, so it runs on a second stream beside the chain and the reduction.
+// Both do the same arithmetic in the same order as the whole pass: the step is bit-identical either way.
+template <int NWB, int PART = 0>
 __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float* __restrict__ V, const float* __restrict__ mV,
                                                                     const float* __restrict__ vV, float* __restrict__ V2,
                                                                     float* __restrict__ mV2, float* __restrict__ vV2,
@@ -1292,7 +1298,7 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
         {
             bias_n = cb[nb * 32 + c];
             xw_n = Xt[nb * 32 + c];
-            if (w == 0 && h == 0 && lvalid) {
+            if (PART != 1 && w == 0 && h == 0 && lvalid) {
                 cm = mC[l];
                 cv = vC[l];
             }
@@ -1304,7 +1310,7 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
 #pragma unroll
                 for (int q = 0; q < 4; ++q) vn[q] = __builtin_nontemporal_load(tVn + q * 64);
             }
-            if (PV_DEC2_VAR != 1) {
+            if (PV_DEC2_VAR != 1 && PART != 1) {
                 const f32x4* tM = reinterpret_cast<const f32x4*>(mV) + tb;
                 const f32x4* tVv = reinterpret_cast<const f32x4*>(vV) + tb;
 #pragma unroll
@@ -1344,7 +1350,7 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
             // mailboxes double as the V^T staging tiles of product (3): nobody overwrites one before all have read it
             sync_ok &= pv_block_sync(&blk_sync[bsub][1], NWB * nsync, lane);
         }
-        if (PV_DEC2_VAR == 1) {  // experiment: the moments requested behind product (1) instead of at the top of the visit
+        if (PV_DEC2_VAR == 1 && PART != 1) {  // experiment: the moments requested behind product (1) instead of at the top of the visit
             const f32x4* tM = reinterpret_cast<const f32x4*>(mV) + tb;
             const f32x4* tVv = reinterpret_cast<const f32x4*>(vV) + tb;
 #pragma unroll
@@ -1365,7 +1371,7 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
         }
         // bias: sum over the 32 samples = 16 regs + the other half-wave; block column 0 updates it
         dbias += __shfl_xor(dbias, 32);
-        if (w == 0 && h == 0 && lvalid) {
+        if (PART != 1 && w == 0 && h == 0 && lvalid) {
             float w_ = bias;
             pv_adam(w_, cm, cv, dbias, alpha, adam);
             cb[l] = w_;
@@ -1374,6 +1380,7 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
         }
         // (3) dg[b][unit] += sum_l da[b][l] * V[unit][l] : M = b, N = unit, K = l.  A needs da^T, B needs V^T (unit on the
         //     lane): both staged through this wave's LDS tiles.
+        if (PART != 2) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             dt[PV_ROW(r, h) * 33 + c] = a[r];                 // [b][l_loc]
@@ -1389,7 +1396,9 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
+        }
         // (4) dV[unit][l] = sum_b g[b][unit] * da[b][l] : M = unit, N = l, K = b ; then Adam on the block
+        if (PART != 1) {
         f32x16 dv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = 0.f;
@@ -1415,6 +1424,7 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
             __builtin_nontemporal_store(m4, oM + q * 64);
             __builtin_nontemporal_store(v4, oVv + q * 64);
         }
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) vv[q] = vn[q];
@@ -1422,6 +1432,7 @@ __global__ __launch_bounds__(PvDec2<NWB>::NW * 64, 2) void pvk_dec2(const float*
         bias = bias_n;
         blk = block_of(it + 1);
     }
+    if (PART == 2) return;  // the loss and dg came from the PART 1 launch
     // ---- per-workgroup reductions (fixed order) ----
     __syncthreads();  // everyone done with g_s / the staging tiles
     PV_WT(0, 2);
