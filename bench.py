@@ -105,9 +105,10 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="drive the staged (SNP-sharded) path even with one rank: rehearses the N > 1 host code")
     ap.add_argument("--lr", type=float, default=1e-4,
-                    help="Adam learning rate of the timed steps.  Keras' default 1e-3 overflows exp(z_log_var) on the "
-                         "second step at 1M SNPs (fan-in 1M x unit Adam steps; the float32 oracle does the same), and a "
-                         "NaN run is not a fair timing, so the bench steps at 1e-4; throughput does not depend on it")
+                    help="Adam learning rate of the timed steps.  At Keras' default 1e-3 the loss explodes within one step "
+                         "at 1M SNPs (fan-in 1M x unit Adam steps; 6.9e5 -> 2.9e10, nan on some data; the float32 oracle "
+                         "does the same, tests/test_gpu_fullsize.py), and such a run is not a fair timing, so the bench "
+                         "steps at 1e-4; throughput does not depend on it")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     if os.environ.get("PVAE_BENCH_TRACE"):  # debugging aid: Python stacks of a stuck rank every N seconds

@@ -186,8 +186,8 @@ def main(argv=None):
     if n_snps * 1e-3 > 300:
         # not a change of behaviour: the reference (Keras Adam, lr 1e-3) does the same
         log(f"WARNING: with {n_snps} SNPs the first Adam steps at Keras' default learning rate 1e-3 move the first layer's "
-            "pre-activations by ~n_snps * lr; float32 exp(z_log_var) was seen to overflow (loss = nan) from the second step "
-            "at 1M SNPs.  If the loss turns nan, thin the input with --max_SNPs.")
+            "pre-activations by ~n_snps * lr: at 1M SNPs the loss was seen to grow by four orders of magnitude within one step "
+            "(float32 oracle and GPU engine alike) and, on some data, to turn inf / nan.  If it does, thin the input with --max_SNPs.")
 
     eng_seed = run_seed
     shuffle_seed = run_seed

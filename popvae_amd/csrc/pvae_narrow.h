@@ -10,10 +10,16 @@
 // D[4 rows][64 columns] += A[4 rows][k] * B[k][64 columns], one contraction step per instruction, 8 cycles each.  With 16-row
 // tiles (v_mfma_f32_16x16x4_f32, two workers, rounds 1-2) a layer was 2048 cycles of each CU's matrix pipe plus ~1.2 us of
 // barrier / epilogue among eight waves; with four rows it is 1024 cycles (tools/mfma4_probe.hip: 1113 measured) on TWO
-// waves -- wave h owns output columns [64 h, 64 h + 64) -- that meet at one cheap two-wave barrier per layer:
-//   * weights go straight from global memory (L2-resident after the warm-up role) into the B operands: lane l of wave h
-//     holds column 64 h + l of the layer's kernel, all kin rows of it (<= 128 registers); the next layer's are loaded
-//     while the current layer computes (another 128 registers: one wave per SIMD, 512-register budget);
+// consumer waves -- wave h owns output columns [64 h, 64 h + 64):
+//   * a worker is four waves.  Waves 2 / 3 are LOADERS: while layer i is computed they copy layer i + 1's kernel (64 KB, 1 KB
+//     chunks of an operand-order copy, below) from L2 into the free slot of a two-slot LDS ring -- all requests first, then the
+//     LDS writes -- and meet the consumers at the one barrier per layer.  Waves 0 / 1 are CONSUMERS: they read their B
+//     operands from the ring slot with ds_read_b128 two 16-step groups ahead of the matrix instructions that use them, and no
+//     vector-memory load sits in their instruction stream at all.  (First version of this round: each compute wave loaded the
+//     next layer's column into 128 registers itself between its matrix instructions -- loads and matrix instructions issue in
+//     order, so a wave stalled on the memory pipe ~1.1 us per layer whatever the interleaving; 23 -> 20 / 17 us per chain with
+//     the split.  A loader that requests two layers ahead into registers was measured slower: its burst of LDS writes lands
+//     where the consumers start reading.)
 //   * activations live in LDS as [k][4 rows]: the A operand of 16 contraction steps is ONE conflict-free ds_read_b32 per lane
 //     (lane 4 b + i holds row i of step 16 j + b; instruction b of the group broadcasts block b: abid = b), and a lane's four
 //     results -- rows 0..3 of its column -- go back as one ds_write_b128;
@@ -52,9 +58,10 @@ struct PvBwdOp {
 };
 #define PVN_BWD_LEAN 10
 
-// Operand-order copies of a narrow kernel W[kin][nout].  The chain kernels feed the matrix instruction straight from
-// global memory: lane l of wave h holds ONE output column, 64 h + l, for every contraction step, and a "chunk" c is the 4
-// consecutive contraction steps 4c .. 4c + 3.  In these copies a wave's chunk is 1 KB contiguous (lane-major, 16 B per lane):
+// Operand-order copies of a narrow kernel W[kin][nout].  Lane l of consumer wave h uses ONE output column, 64 h + l, for every
+// contraction step, and a "chunk" c is the 4 consecutive contraction steps 4c .. 4c + 3 of the 64 columns of one wave.  In these
+// copies a chunk is 1 KB contiguous (lane-major, 16 B per lane), so a loader wave moves it with one global_load_dwordx4 and one
+// ds_write_b128, and the consumer gets four steps of its column with one ds_read_b128 from the same offsets:
 //   forward   (out = in * W,     column = output unit n)  Wf[((h * kin/4  + c) * 64 + l) * 4 + e] = W[4c + e][64 h + l]
 //   backward  (dIn = dpre * W^T, column = input unit k)   Wb[((h * nout/4 + c) * 64 + l) * 4 + e] = W[64 h + l][4c + e]
 // Columns beyond the layer (64 h + l >= nout resp. kin) hold zeros.  pvk_narrow_adam keeps the copies in step with W;

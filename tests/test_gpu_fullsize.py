@@ -242,7 +242,8 @@ def test_snp_shards_add_up_at_full_size(L, W, D):
         e.close()
 
 
-def test_headline_shape_at_keras_default_lr():
+@pytest.mark.parametrize("L,W,D,steps", [(1_000_000, 128, 6, 3), (200_000, 256, 8, 8)])
+def test_headline_shape_at_keras_default_lr(L, W, D, steps):
     """BASELINE's headline shape (1M SNPs, depth 6, width 128, batch 32) at the reference's own optimizer defaults
     (`vae.compile(optimizer="adam")`, popvae.py:426: lr = 1e-3).  With a fan-in of 1M the first Adam step (every first-layer
     weight moves by ~lr in the direction of its gradient's sign) throws the pre-activations out by hundreds, and the loss
@@ -250,8 +251,15 @@ def test_headline_shape_at_keras_default_lr():
     2.3483e10 at step 2): a property of the model at this scale, which bench.py avoids by stepping at lr = 1e-4.  The engine
     must do what the float32 oracle does at the same settings: the same losses while they are finite (step 0 to 1e-4; later
     steps, where the float32 rounding of 128M updates of +-lr is amplified by the fan-in, to 5e-3), and non-finite at the same
-    step if at all."""
-    L, W, D, K, N, n = 1_000_000, 128, 6, 2, 40, 32
+    step if at all.
+    Second case: the 256 x 8 cell of BASELINE config 5 (200 k SNPs), whose validation loss came out NaN from the first epoch on
+    when the grid was run as a run at every default (profiles/r03_v2_grid_c5.json: an empty val_loss in _param_grid.csv, which
+    is what pandas writes for a NaN).  On this test's data the cell is in the same unstable regime without leaving float32:
+    the KL term jumps 0.14 -> 119 -> 3886 -> 4502 -> 19898 over the first five steps, engine and float32 oracle agree to 3e-5
+    over the first eight steps and then drift apart as their rounding differences are amplified (3e-3 at step 8, per cent by
+    step 15; both finite over 40 steps).  The test holds the eight steps to 2e-4; what the grid's NaN is beyond "this model is
+    unstable at lr = 1e-3 and this fan-in" stays unpinned."""
+    K, N, n = 2, 40, 32
     codes = _codes(N, L, seed=128)
     w = O.init_weights(L, W, D, K, seed=7, dtype=np.float32)
     e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=32, seed=0, lr=1e-3)
@@ -261,18 +269,21 @@ def test_headline_shape_at_keras_default_lr():
     g = np.random.default_rng(5)
     got, want = [], []
     with np.errstate(all="ignore"):
-        for step in range(3):
+        for step in range(steps):
             rows = g.choice(N, n, replace=False).astype(np.int32)
             eps = g.normal(size=(n, K)).astype(np.float32)
             got.append(e.train_step(rows, eps))
             lo, c = O.train_step(w, opt, (codes[rows] * np.float32(0.5)).astype(np.float32), eps, D, K)
             want.append((float(lo), float(c["recon"].mean()), float(c["kl"].mean())))
     e.close()
-    print("engine", got, "oracle", want)
+    for step, (a, b) in enumerate(zip(got, want)):
+        print(step, "engine", a, "oracle", b)
     for step, (a, b) in enumerate(zip(got, want)):
         assert np.isfinite(a[0]) == np.isfinite(b[0]), (step, a, b)
         if np.isfinite(b[0]):
-            tol = RTOL if step == 0 else 5e-3
+            tol = RTOL if step == 0 else 5e-3 if W == 128 else 2e-4
             assert abs(a[0] - b[0]) <= tol * abs(b[0]), (step, a, b)
             assert abs(a[1] - b[1]) <= tol * abs(b[1]), (step, a, b)
+    if W != 128:
+        return
     assert want[1][0] > 1e3 * want[0][0]  # the blow-up itself: what makes lr = 1e-3 unusable at this fan-in

@@ -7,7 +7,7 @@ import json
 import sqlite3
 import sys
 
-KEYS = {"enc_fwd": "pvk_enc_fwd<", "dec": "pvk_dec2<4>", "enc_bwd": "pvk_enc_bwd<4, 0, 1,", "dec_eval": "pvk_dec<4, 0, 0>"}
+KEYS = {"enc_fwd": "pvk_enc_fwd<", "dec": "pvk_dec2<4, 0>", "enc_bwd": "pvk_enc_bwd<4, 0, 1,", "dec_eval": "pvk_dec<4, 0, 0>"}
 SHAPE = sys.argv[4] if len(sys.argv) > 4 else "C4"
 
 
