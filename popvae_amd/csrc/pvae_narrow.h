@@ -12,8 +12,8 @@
 // barrier / epilogue among eight waves; with four rows it is 1024 cycles (tools/mfma4_probe.hip: 1113 measured) on TWO
 // consumer waves -- wave h owns output columns [64 h, 64 h + 64):
 //   * a worker is four waves.  Waves 2 / 3 are LOADERS: while layer i is computed they copy layer i + 1's kernel (64 KB, 1 KB
-//     chunks of an operand-order copy, below) from L2 into the free slot of a two-slot LDS ring -- all requests first, then the
-//     LDS writes -- and meet the consumers at the one barrier per layer.  Waves 0 / 1 are CONSUMERS: they read their B
+//     chunks of an operand-order copy, below) from L2 into the free slot of a two-slot LDS ring -- with LDS-direct loads
+//     (global_load_lds_dwordx4), nothing passes through registers -- and meet the consumers at the one barrier per layer.  Waves 0 / 1 are CONSUMERS: they read their B
 //     operands from the ring slot with ds_read_b128 two 16-step groups ahead of the matrix instructions that use them, and no
 //     vector-memory load sits in their instruction stream at all.  (First version of this round: each compute wave loaded the
 //     next layer's column into 128 registers itself between its matrix instructions -- loads and matrix instructions issue in
@@ -149,10 +149,29 @@ __device__ unsigned long long pvn_trace_buf[2048];
 // from the ring, one two-instruction-group ahead -- and the four meet at one barrier per op.
 #define PVQ_SLOT_FLOATS (128 * 128)  // one kernel copy: up to 64 chunks of 1 KB
 
-// loader wave lw (0 / 1) copies chunks lw, lw + 2, ... of a copy of `N` chunks per loader: all loads first, then the LDS writes.
+// loader wave lw (0 / 1) copies chunks lw, lw + 2, ... of a kernel copy.  The register-staged form (PVQ_DMA 0: all loads first,
+// then the LDS writes) is kept for comparison: 20.2 / 22.9 us per chain against 19.0 / 22.2 with LDS-direct loads.
 // (Requesting op i + 2's kernel into registers an op ahead and writing it at the top of op i + 1 was built and measured slower,
 // 1.8 us per op against 1.3: the 32 ds_write_b128 of the two loaders -- 13 cycles each through the VGPR-to-LDS path -- then
 // land in one burst exactly where the consumers start reading their operands.)
+#ifndef PVQ_DMA
+#define PVQ_DMA 1
+#endif
+#if PVQ_DMA
+// LDS-direct loads (global_load_lds_dwordx4: lane l's 16 bytes land at the LDS base in M0 + 16 l -- tools/lds_dma_probe.hip):
+// a chunk goes from L2 into the ring without passing through registers, and the LDS writes trickle in as the data arrives
+// instead of following the last load as a burst of 32 ds_write_b128 per wave (~0.25 us of a 1.3 us op).
+__device__ __forceinline__ void pvq_fill_op(const float* __restrict__ src, int nchunks, float* slot, int lw, int lane) {
+    typedef __attribute__((address_space(1))) const void gptr;
+    typedef __attribute__((address_space(3))) void lptr;
+    const float* s = src + 256 * lw + 4 * lane;
+    float* d = slot + 256 * lw;
+    const int n = nchunks >> 1;  // chunks per loader: contraction lengths and widths are multiples of 32, so a multiple of 4
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_global_load_lds((gptr*)(s + 512 * i), (lptr*)(d + 512 * i), 16, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the chunks are in LDS
+}
+#else
 template <int N>
 __device__ __forceinline__ void pvq_fill(const float* __restrict__ src, float* slot, int lw, int lane) {
     f32x4 v[N];
@@ -171,6 +190,7 @@ __device__ __forceinline__ void pvq_fill_op(const float* __restrict__ src, int n
         default: pvq_fill<32>(src, slot, lw, lane); break;
     }
 }
+#endif
 // 16 contraction steps: instruction b takes the A operand of block b (lanes 4b .. 4b + 3: rows 0..3 of step 16 j + b) for all
 // 64 columns (cbsz = 4, abid = b); four accumulators in rotation keep dependent instructions four apart
 template <int B>
@@ -298,7 +318,9 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
             }
         } else if (h * 64 < N) {
             PVN_T(i * 8 + 0);
-            // this op's bias: issued here, complete when the epilogue needs it (op.b is never null)
+            // this op's bias: issued here, complete when the epilogue needs it (op.b is never null).  (Requested one op ahead,
+            // before the barrier -- and likewise the Y words of the backward chain's epilogue -- was measured slower: 20.1 / 22.9
+            // against 19.0 / 22.2 us per chain.)
             const float bcur = pvn_g(op.b)[n < N ? n : 0];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             if (op.kind == PVN_BIAS_ACT) {
