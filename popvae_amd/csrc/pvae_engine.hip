@@ -125,6 +125,7 @@ struct pvae_engine {
     // pvk_enc_bwd <.., T>, pvk_dec3<T> and 2 T chain workers; activation buffers hold 32 T rows.  T == 1: off.
     int T = 1;
     int dec3_wgs = 0;          // grid of pvk_dec3<T> (one workgroup per CU, 4 / T subtiles per iteration)
+    bool dec3b = true;         // T = 4: pvk_dec3b (logits and dV on the bf16 matrix pipe) instead of pvk_dec3<4>
     int dece_mt_wgs = 0;       // grid of pvk_dec_eval_mt<T> (two workgroups per CU: the T g tiles are 16.5 T KB of LDS)
     int encf_mt_wgs = 0;       // grid of pvk_enc_fwd<4, T> (T > 1: no fused forward to match, two workgroups on every CU) = its partial tiles
     int encb_parts = 0;        // partial tiles [32][Wp] the fused forward of pvk_enc_bwd leaves in encpart (one per subtile slot)
@@ -366,6 +367,9 @@ int setup_kernel_attrs(pvae_engine* e) {
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_GRAD, 0>), lds_enc_bwd(e->Wp)));         \
     HIPCHK(allow_lds((pvk_enc_bwd<N, PV_MODE_TRAIN_ACC, 0>), lds_enc_bwd(e->Wp)));
 #define PV_ATTR_MT(TT)                                                                                     \
+    HIPCHK(allow_lds((pvk_dec3b<PV_MODE_TRAIN>), PvDec3b::lds()));                                          \
+    HIPCHK(allow_lds((pvk_dec3b<PV_MODE_GRAD>), PvDec3b::lds()));                                           \
+    HIPCHK(allow_lds((pvk_dec3b<PV_MODE_TRAIN_ACC>), PvDec3b::lds()));                                      \
     HIPCHK(allow_lds((pvk_dec3<TT, PV_MODE_TRAIN>), PvDec3<TT>::lds()));                                    \
     HIPCHK(allow_lds((pvk_dec3<TT, PV_MODE_GRAD>), PvDec3<TT>::lds()));                                     \
     HIPCHK(allow_lds((pvk_dec3<TT, PV_MODE_TRAIN_ACC>), PvDec3<TT>::lds()));                                \
@@ -1017,9 +1021,22 @@ int multi_tile_launches(pvae_engine* e, int row_offset, float* d_out3, int mode)
                        upd ? e->cout.v : nul, (const float*)e->g[e->D - 1], (const uint64_t*)e->Xt, e->nblk, (int)e->L,              \
                        (const PvStep*)e->st, e->adam, e->dgpart, e->losspart, e->ts4, (const float*)(mode == 4 ? e->Vout.g : nul),   \
                        (const float*)(mode == 4 ? e->cout.g : nul))
-        if (km == PV_MODE_GRAD) PV_DEC3_LAUNCH(PV_MODE_GRAD);
+        // four tiles: logits and dV on the bf16 matrix pipe at f32 accuracy (pvk_dec3b); PVAE_NO_DEC3B=1: the fp32 kernel
+#define PV_DEC3B_LAUNCH(MD)                                                                                                         \
+    hipLaunchKernelGGL((pvk_dec3b<MD>), dim3(wgs), dim3(256), PvDec3b::lds(), e->stream, (const float*)e->Vout.w,                    \
+                       (const float*)(upd ? e->Vout.m : nul), (const float*)(upd ? e->Vout.v : nul), upd ? e->Vout.w2 : nul,         \
+                       upd ? e->Vout.m2 : e->Vout.g, upd ? e->Vout.v2 : nul, e->cout.w, upd ? e->cout.m : e->cout.g,                 \
+                       upd ? e->cout.v : nul, (const float*)e->g[e->D - 1], (const uint64_t*)e->Xt, e->nblk, (int)e->L,              \
+                       (const PvStep*)e->st, e->adam, e->dgpart, e->losspart, e->ts4, (const float*)(mode == 4 ? e->Vout.g : nul),   \
+                       (const float*)(mode == 4 ? e->cout.g : nul))
+        if (T == 4 && PV_MT_BF16 && e->dec3b) {
+            if (km == PV_MODE_GRAD) PV_DEC3B_LAUNCH(PV_MODE_GRAD);
+            else if (km == PV_MODE_TRAIN_ACC) PV_DEC3B_LAUNCH(PV_MODE_TRAIN_ACC);
+            else PV_DEC3B_LAUNCH(PV_MODE_TRAIN);
+        } else if (km == PV_MODE_GRAD) PV_DEC3_LAUNCH(PV_MODE_GRAD);
         else if (km == PV_MODE_TRAIN_ACC) PV_DEC3_LAUNCH(PV_MODE_TRAIN_ACC);
         else PV_DEC3_LAUNCH(PV_MODE_TRAIN);
+#undef PV_DEC3B_LAUNCH
 #undef PV_DEC3_LAUNCH
         if (upd) e->Vout.swap();
         hipLaunchKernelGGL(pvk_reduce_parts, dim3(PV_REDUCE_GRID(nR)), dim3(256), 0, e->stream, e->dgpart, wgs, nR, 1.0f,
@@ -1552,6 +1569,7 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
         e->dec3_wgs = std::max(1, std::min(cus2, (e->nblk + spw - 1) / spw));
     }
     e->fuse_fwd = !getenv("PVAE_NO_FUSE_FWD");
+    e->dec3b = !getenv("PVAE_NO_DEC3B");
     e->use_xrn = getenv("PVAE_XRN") != nullptr;
     e->dgpart_cap = std::max((int64_t)std::max(e->dec_wgs, e->dec2_wgs) * 32 * e->Wp, (int64_t)e->dec3_wgs * 32 * e->T * e->Wp);
     CK(allocf(e, &e->dgpart, e->dgpart_cap));

@@ -1812,6 +1812,299 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// pvk_dec3 at four row tiles with two of its three products on the bf16 matrix pipe at f32 accuracy (round 3).  At T = 4
+// pvk_dec3<4> is bound by the fp32 matrix pipe (192 instructions of ~74 cycles per visit, 14 300 of 20 090 cycles).  Here:
+//   (1) logits of tile t = g_t . V: six bf16 term products (pv_split3, as pvk_dec_eval_bf): V is cut in registers, the terms of
+//       g come from the operand-order table in LDS ([tile][block column][instruction][term][lane] x 16 B, 24 KB per tile);
+//   (3) dg += da . V^T stays on the fp32 instruction (both operands would have to be re-cut AND transposed every visit);
+//   (4) dV = sum over ALL tiles of g_t^T . da_t as ONE contraction over the 128 rows, by the wave that updates the block column:
+//       wave t owns block column t of the subtile (CPW = 1 at T = 4).  Its A operands -- the three terms of g^T for its 32 units
+//       and all 128 rows -- never change during the launch and live in 96 registers; the B operands are the terms of every
+//       tile's da, which that tile's wave posts in operand order (the accumulator layout of product (1) IS the B layout of this
+//       contraction: no transposition), 6 KB per tile.  The sum over the tiles happens inside the accumulator: no dV fragments
+//       through LDS (64 KB per visit in pvk_dec3), no second sync point.
+// One sync point per visit (C: da terms, V^T columns and bias parts posted), one counter that is only waited for a visit later (B).
+// LDS: g table 96 KB + per wave { da^T [32][33], V^T column [32][33] } + da terms 24 KB + bias parts = 154 KB.
+// ---------------------------------------------------------------------------------------------
+struct PvDec3b {
+    static constexpr int T = 4, NW = 4, WP = 128;
+    static constexpr int GTAB_F = T * 4 * 2 * 3 * 64 * 4;  // floats of the g operand table
+    static constexpr int WAVE_F = 2 * 32 * 33;             // da^T + one V^T column
+    static constexpr int POST_F = T * 2 * 3 * 64 * 4;      // da terms of the four tiles
+    static constexpr size_t lds() {
+        const size_t work = (size_t)GTAB_F + NW * WAVE_F + POST_F + 2 * NW * 32;
+        const size_t red = (size_t)NW * 4 * 1024 + NW;
+        return (work > red ? work : red) * 4;
+    }
+};
+template <int MODE = PV_MODE_TRAIN>
+__global__ __launch_bounds__(256, 1) void pvk_dec3b(const float* __restrict__ V, const float* __restrict__ mV,
+                                                    const float* __restrict__ vV, float* __restrict__ V2, float* __restrict__ mV2,
+                                                    float* __restrict__ vV2, float* __restrict__ cb, float* __restrict__ mC,
+                                                    float* __restrict__ vC, const float* __restrict__ g,
+                                                    const uint64_t* __restrict__ Xt, int nblk, int L, const PvStep* st, PvAdam adam,
+                                                    float* __restrict__ dgpart, float* __restrict__ losspart, int ts,
+                                                    const float* __restrict__ gV, const float* __restrict__ gC) {
+    using G = PvDec3b;
+    constexpr int T = G::T, NW = G::NW, WP = G::WP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    pv_u32x4* gop = reinterpret_cast<pv_u32x4*>(smem);  // [T][4 w][2 i][3 term][64 lanes]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int t = wave;  // this wave's row tile, and the block column it updates
+    float* waves_s = smem + G::GTAB_F;
+    float* dt = waves_s + wave * G::WAVE_F;  // [32][33] da^T of this tile
+    float* vtc = dt + 32 * 33;               // [32][33] V^T of block column t
+    pv_u32x4* dpost = reinterpret_cast<pv_u32x4*>(waves_s + NW * G::WAVE_F);  // [T][2 q][3 term][64 lanes]
+    float* dbias_s = waves_s + NW * G::WAVE_F + G::POST_F;                    // [2][NW][32]
+    const int nrows = st->nrows;
+    const float inv_b = st->inv_b, alpha = st->alpha;
+    const int bce_probs = PV_BCE_MODE(st);
+    const bool acc_grads = MODE == PV_MODE_GRAD && st->acc != 0;
+    __shared__ int sync_b, sync_c;  // arrivals of the four waves (only ever grow)
+    if (tid == 0) sync_b = sync_c = 0;
+    bool sync_ok = true;
+
+    auto subtile_of = [&](int it) { return it * (int)gridDim.x + (int)blockIdx.x; };
+    f32x4 vv[4][4], vn[4][4];
+    uint64_t xw = 0, xw_n = 0;
+    float bias = 0.f, bias_n = 0.f;
+    int blk = subtile_of(0);
+    if (blk < nblk) {
+        const f32x4* tV = reinterpret_cast<const f32x4*>(V) + (int64_t)blk * ts + lane;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vv[w][q] = __builtin_nontemporal_load(tV + (w * 4 + q) * 64);
+        xw = Xt[((int64_t)t * nblk + blk) * 32 + c];
+        bias = cb[blk * 32 + c];
+    }
+    // g operand table of product (1): lane (b, kg) of instruction (w, i) holds units 32 w + ROW(8 i + j, kg), j = 0 .. 7
+    for (int e = tid; e < T * 4 * 2 * 64; e += NW * 64) {
+        const int ln = e & 63, i = (e >> 6) & 1, w = (e >> 7) & 3, t2 = e >> 9, cc = ln & 31, hh = ln >> 5;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = g[(32 * t2 + cc) * WP + w * 32 + PV_ROW(8 * i + j, hh)];
+        pv_u32x4 th, tm, tl;
+        pv_split3(x, th, tm, tl);
+        pv_u32x4* dst = gop + (((t2 * 4 + w) * 2 + i) * 3) * 64 + ln;
+        dst[0] = th;
+        dst[64] = tm;
+        dst[128] = tl;
+    }
+    // A operands of product (4), resident: lane (unit 32 t + c, kg = h) of instruction (t2, q) holds rows 32 t2 + ROW(8 q + j, h)
+    pv_u32x4 gth[T][2], gtm[T][2], gtl[T][2];
+#pragma unroll
+    for (int t2 = 0; t2 < T; ++t2)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = g[(32 * t2 + PV_ROW(8 * q + j, h)) * WP + 32 * t + c];
+            pv_split3(x, gth[t2][q], gtm[t2][q], gtl[t2][q]);
+        }
+    __syncthreads();
+
+    f32x16 dg[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dg[w][r] = 0.f;
+    float lossacc = 0.f;
+
+    for (int it = 0; blk < nblk; ++it) {
+        const int nb = subtile_of(it + 1) < nblk ? subtile_of(it + 1) : blk;  // past the end: a harmless re-read
+        const int l = blk * 32 + c;
+        const bool lvalid = l < L;
+        const int64_t tb = (int64_t)blk * ts + lane;
+        // requests of this visit (the bias word first: loads return in order, so it has landed before the next visit's sync point,
+        // behind which wave 0 rewrites the bias in place)
+        bias_n = cb[nb * 32 + c];
+        xw_n = Xt[((int64_t)t * nblk + nb) * 32 + c];
+        const int lc = l < L ? l : L - 1;
+        float cm = 0.f, cv = 0.f;
+        if (MODE != PV_MODE_GRAD) {
+            cm = mC[lc];
+            cv = vC[lc];
+        }
+        f32x4 mq[4], vq[4], gq[4];
+        const f32x4* tVn = reinterpret_cast<const f32x4*>(V) + (int64_t)nb * ts + lane;
+        const int64_t go = (int64_t)blk * (4 * 256) + (t * 4) * 64 + lane;  // gradient dumps are plain tiles
+        const uint64_t xs = xw >> (8 * h);
+        const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
+        // (1) logits of tile t on the bf16 pipe; the next visit's V is requested between the instructions
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                vn[w][2 * i] = __builtin_nontemporal_load(tVn + (w * 4 + 2 * i) * 64);
+                vn[w][2 * i + 1] = __builtin_nontemporal_load(tVn + (w * 4 + 2 * i + 1) * 64);
+                const float x[8] = {vv[w][2 * i][0], vv[w][2 * i][1], vv[w][2 * i][2], vv[w][2 * i][3],
+                                    vv[w][2 * i + 1][0], vv[w][2 * i + 1][1], vv[w][2 * i + 1][2], vv[w][2 * i + 1][3]};
+                pv_u32x4 bh, bm, bl;
+                pv_split3(x, bh, bm, bl);
+                const pv_u32x4* src = gop + (((t * 4 + w) * 2 + i) * 3) * 64 + lane;
+                const pv_u32x4 ah = src[0], am = src[64], al = src[128];
+                a = pv_mfma_bf16(al, bh, a);
+                a = pv_mfma_bf16(ah, bl, a);
+                a = pv_mfma_bf16(am, bm, a);
+                a = pv_mfma_bf16(am, bh, a);
+                a = pv_mfma_bf16(ah, bm, a);
+                a = pv_mfma_bf16(ah, bh, a);
+            }
+        // (2) sigmoid / BCE / dlogits of tile t
+        float dbias = 0.f;
+        pv_sigmoid_bce(bce_probs, (blk * 32 + 32 <= L) && (32 * t + 32 <= nrows), true, a, bias, lo, hi, h, 32 * t, nrows, lvalid,
+                       inv_b, lossacc, dbias);
+        dbias += __shfl_xor(dbias, 32);
+        // everything the other waves read of last visit's posts has been read (their arrival at B) before it is overwritten
+        sync_ok &= pv_block_wait(&sync_b, T * it);
+        float* dbias_v = dbias_s + (it & 1) * NW * 32;
+        if (h == 0) dbias_v[wave * 32 + c] = dbias;
+        // da of this tile: its three bf16 terms in the B-operand order of product (4) (lane (l, kg = h): rows ROW(8 q + j, h)),
+        // da^T in f32 for product (3), and this wave's block column of V^T
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float x[8] = {a[8 * q], a[8 * q + 1], a[8 * q + 2], a[8 * q + 3], a[8 * q + 4], a[8 * q + 5], a[8 * q + 6], a[8 * q + 7]};
+            pv_u32x4 dh, dm, dl;
+            pv_split3(x, dh, dm, dl);
+            pv_u32x4* dst = dpost + ((t * 2 + q) * 3) * 64 + lane;
+            dst[0] = dh;
+            dst[64] = dm;
+            dst[128] = dl;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dt[PV_ROW(r, h) * 33 + c] = a[r];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w != t) continue;  // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vtc[PV_ROW(r, h) * 33 + c] = vv[w][r >> 2][r & 3];
+        }
+        pv_block_arrive(&sync_c, lane);
+        // what the update of block column t reads besides V: the moments (Adam), the dump (accumulate variants)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (MODE == PV_MODE_GRAD) {
+                gq[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mV2) + go + q * 64);
+            } else {
+                mq[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mV) + tb + (t * 4 + q) * 64);
+                vq[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vV) + tb + (t * 4 + q) * 64);
+                if (MODE == PV_MODE_TRAIN_ACC) gq[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gV) + go + q * 64);
+            }
+        }
+        sync_ok &= pv_block_wait(&sync_c, T * (it + 1));
+        // (3) dg[b][unit] += sum_l da[b][l] V[unit][l] (fp32 instruction): A = da^T of this tile, B = V^T column w (wave w's)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float* vt = waves_s + w * G::WAVE_F + 32 * 33;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dg[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(dt[c * 33 + PV_ROW(r, h)], vt[c * 33 + PV_ROW(r, h)], dg[w], 0, 0, 0);
+        }
+        // (4) dV of block column t over all 128 rows on the bf16 pipe: tiles in order, one accumulator
+        f32x16 dv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dv[r] = 0.f;
+#pragma unroll
+        for (int t2 = 0; t2 < T; ++t2)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const pv_u32x4* src = dpost + ((t2 * 2 + q) * 3) * 64 + lane;
+                const pv_u32x4 dh = src[0], dm = src[64], dl = src[128];
+                dv = pv_mfma_bf16(gtl[t2][q], dh, dv);
+                dv = pv_mfma_bf16(gth[t2][q], dl, dv);
+                dv = pv_mfma_bf16(gtm[t2][q], dm, dv);
+                dv = pv_mfma_bf16(gtm[t2][q], dh, dv);
+                dv = pv_mfma_bf16(gth[t2][q], dm, dv);
+                dv = pv_mfma_bf16(gth[t2][q], dh, dv);
+            }
+        // Adam on block column t (or the gradient dump)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w != t) continue;  // wave-uniform: vv[t] without a dynamic register index
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 gsum = {dv[4 * q], dv[4 * q + 1], dv[4 * q + 2], dv[4 * q + 3]};
+                const int off = (w * 4 + q) * 64;
+                if (MODE == PV_MODE_GRAD) {
+                    if (acc_grads) gsum += gq[q];
+                    __builtin_nontemporal_store(gsum, reinterpret_cast<f32x4*>(mV2) + go + q * 64);
+                    continue;
+                }
+                if (MODE == PV_MODE_TRAIN_ACC) gsum += gq[q];
+                f32x4 wq = vv[w][q], m4 = mq[q], v4 = vq[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float w_ = wq[e], m_ = m4[e], v_ = v4[e];
+                    pv_adam(w_, m_, v_, gsum[e], alpha, adam);
+                    wq[e] = w_;
+                    m4[e] = m_;
+                    v4[e] = v_;
+                }
+                __builtin_nontemporal_store(wq, reinterpret_cast<f32x4*>(V2) + tb + off);
+                __builtin_nontemporal_store(m4, reinterpret_cast<f32x4*>(mV2) + tb + off);
+                __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(vV2) + tb + off);
+            }
+        }
+        if (t == 0 && h == 0 && lvalid) {  // the output bias: sum of the tiles' parts, in tile order
+            float gb = dbias_v[c];
+#pragma unroll
+            for (int t2 = 1; t2 < T; ++t2) gb += dbias_v[t2 * 32 + c];
+            if (MODE == PV_MODE_GRAD) {
+                mC[l] = acc_grads ? mC[l] + gb : gb;
+            } else {
+                if (MODE == PV_MODE_TRAIN_ACC) gb += gC[l];
+                float w_ = bias;
+                pv_adam(w_, cm, cv, gb, alpha, adam);
+                cb[l] = w_;
+                mC[l] = cm;
+                vC[l] = cv;
+            }
+        }
+        pv_block_arrive(&sync_b, lane);
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vv[w][q] = vn[w][q];
+        xw = xw_n;
+        bias = bias_n;
+        blk = subtile_of(it + 1);
+    }
+    // ---- per-workgroup reductions (fixed order) ----
+    __syncthreads();
+    float* red = smem;  // [NW][4][16][64], then [NW] loss
+    lossacc += __shfl_xor(lossacc, 1);
+    lossacc += __shfl_xor(lossacc, 2);
+    lossacc += __shfl_xor(lossacc, 4);
+    lossacc += __shfl_xor(lossacc, 8);
+    lossacc += __shfl_xor(lossacc, 16);
+    lossacc += __shfl_xor(lossacc, 32);
+    if (!sync_ok) lossacc = __builtin_nanf("");  // a sync point gave up: make the step loudly wrong
+    float* lred = red + NW * 4 * 1024;
+    if (lane == 0) lred[wave] = lossacc;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * 4 + w) * 16 + r) * 64 + lane] = dg[w][r];
+    __syncthreads();
+    if (tid == 0) {
+        float sacc = 0.f;
+        for (int w2 = 0; w2 < NW; ++w2) sacc += lred[w2];
+        losspart[blockIdx.x] = sacc;
+    }
+    // dgpart[workgroup][32 T][WP]: tile t2's rows = wave t2's fragments
+    float* dgp = dgpart + (int64_t)blockIdx.x * (32 * T * WP);
+    for (int e = tid; e < T * 4 * 1024; e += NW * 64) {
+        const int t2 = e / 4096, f = e % 4096;  // tile, (block column, fragment element)
+        const int w = f >> 10, r = (f >> 6) & 15, ln = f & 63;
+        dgp[(32 * t2 + PV_ROW(r, ln >> 5)) * WP + w * 32 + (ln & 31)] = red[t2 * 4096 + f];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Wide decoder, evaluation pass (loss only: validation batches, popvae.py:496) for T row tiles, width 128: pvk_dec<4, 0, ..>'s
 // read-only sweep with the subtile held in registers while every tile's logits and BCE terms are formed -- V is read once
 // per 32 T rows.  One wave per subtile, round-robin; LDS: the T g tiles.  losspart[workgroup] = summed BCE of its SNPs.
