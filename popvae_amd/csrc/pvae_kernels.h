@@ -292,6 +292,30 @@ __device__ __forceinline__ void pv_split3(const float (&x)[8], pv_u32x4& hi, pv_
         lo[i] = pv_pack_hi16(r2[2 * i], r2[2 * i + 1]);
     }
 }
+// pv_split3 in six stages of 4 .. 8 VALU instructions, to be placed by hand between matrix instructions (one stage hides behind
+// one v_mfma_f32_32x32x16_bf16, which issues every 32 cycles): stages 0-3 cut two values each, 4 packs hi and mid, 5 packs lo
+struct PvCut3 {
+    float x[8], r1[8], r2[8];
+};
+template <int STAGE>
+__device__ __forceinline__ void pv_cut_stage(PvCut3& c, pv_u32x4& hi, pv_u32x4& mid, pv_u32x4& lo) {
+    if constexpr (STAGE < 4) {
+#pragma unroll
+        for (int i = 2 * STAGE; i < 2 * STAGE + 2; ++i) {
+            c.r1[i] = c.x[i] - __uint_as_float(__float_as_uint(c.x[i]) & 0xFFFF0000u);
+            c.r2[i] = c.r1[i] - __uint_as_float(__float_as_uint(c.r1[i]) & 0xFFFF0000u);
+        }
+    } else if constexpr (STAGE == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hi[i] = pv_pack_hi16(c.x[2 * i], c.x[2 * i + 1]);
+            mid[i] = pv_pack_hi16(c.r1[2 * i], c.r1[2 * i + 1]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lo[i] = pv_pack_hi16(c.r2[2 * i], c.r2[2 * i + 1]);
+    }
+}
 __device__ __forceinline__ f32x16 pv_mfma_bf16(pv_u32x4 a, pv_u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pv_bf16x8, a), __builtin_bit_cast(pv_bf16x8, b), c, 0, 0, 0);
 }
@@ -1812,24 +1836,31 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3(const float* __restrict__ V, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// pvk_dec3 at four row tiles with two of its three products on the bf16 matrix pipe at f32 accuracy (round 3).  At T = 4
+// pvk_dec3 at four row tiles with its three products on the bf16 matrix pipe at f32 accuracy (round 3).  At T = 4
 // pvk_dec3<4> is bound by the fp32 matrix pipe (192 instructions of ~74 cycles per visit, 14 300 of 20 090 cycles).  Here:
 //   (1) logits of tile t = g_t . V: six bf16 term products (pv_split3, as pvk_dec_eval_bf): V is cut in registers, the terms of
 //       g come from the operand-order table in LDS ([tile][block column][instruction][term][lane] x 16 B, 24 KB per tile);
-//   (3) dg += da . V^T stays on the fp32 instruction (both operands would have to be re-cut AND transposed every visit);
+//   (3) dg += da . V^T: both operands have the SNP on the lane where the contraction wants it in registers.  Each goes through a
+//       private f32 scratch in LDS once (written by rows of registers, read back eight SNPs a lane) and is cut into terms: da^T of
+//       tile t stays in wave t's registers (the A operand), V^T of block column t is posted in operand order for all four waves;
 //   (4) dV = sum over ALL tiles of g_t^T . da_t as ONE contraction over the 128 rows, by the wave that updates the block column:
 //       wave t owns block column t of the subtile (CPW = 1 at T = 4).  Its A operands -- the three terms of g^T for its 32 units
 //       and all 128 rows -- never change during the launch and live in 96 registers; the B operands are the terms of every
 //       tile's da, which that tile's wave posts in operand order (the accumulator layout of product (1) IS the B layout of this
 //       contraction: no transposition), 6 KB per tile.  The sum over the tiles happens inside the accumulator: no dV fragments
 //       through LDS (64 KB per visit in pvk_dec3), no second sync point.
-// One sync point per visit (C: da terms, V^T columns and bias parts posted), one counter that is only waited for a visit later (B).
-// LDS: g table 96 KB + per wave { da^T [32][33], V^T column [32][33] } + da terms 24 KB + bias parts = 154 KB.
+// One sync point per visit (C: da terms, V^T terms and bias parts posted), one counter that is only waited for a visit later (B).
+// Per visit (tools/trace_dec3.py, 1M SNPs): 13 600 cycles at ~2.0-2.3 GHz against 20 090 for pvk_dec3<4> -- 4 600 of matrix pipe,
+// the rest VALU (cutting operands ~700 instructions, sigmoid / BCE 1 600 cycles, Adam), LDS round trips and the sync point, none of
+// it overlapped with the matrix instructions: one wave per SIMD on 410 registers.  Two waves per SIMD (a matrix wave and a helper
+// wave per tile) would overlap them; the g table's 96 KB of LDS and the 256-register budget are what stand in the way.
+// LDS: g table 96 KB + V^T terms 24 KB (each wave's 6 KB double as its transposition scratch) + da terms 24 KB + bias parts = 145 KB.
 // ---------------------------------------------------------------------------------------------
 struct PvDec3b {
     static constexpr int T = 4, NW = 4, WP = 128;
     static constexpr int GTAB_F = T * 4 * 2 * 3 * 64 * 4;  // floats of the g operand table
-    static constexpr int WAVE_F = 2 * 32 * 33;             // da^T + one V^T column
+    static constexpr int RS = 36;                          // row stride of the f32 transposition scratch (16-byte rows)
+    static constexpr int WAVE_F = 2 * 3 * 64 * 4;          // V^T terms of one block column; doubles as the transposition scratch
     static constexpr int POST_F = T * 2 * 3 * 64 * 4;      // da terms of the four tiles
     static constexpr size_t lds() {
         const size_t work = (size_t)GTAB_F + NW * WAVE_F + POST_F + 2 * NW * 32;
@@ -1852,8 +1883,11 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3b(const float* __restrict__ V,
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int t = wave;  // this wave's row tile, and the block column it updates
     float* waves_s = smem + G::GTAB_F;
-    float* dt = waves_s + wave * G::WAVE_F;  // [32][33] da^T of this tile
-    float* vtc = dt + 32 * 33;               // [32][33] V^T of block column t
+    // this wave's 6 KB: the three terms of V^T of block column t in the B-operand order of product (3), [2 i][3 term][64 lanes]
+    // x 16 B, read by all four waves; before they are written the same bytes serve as the wave's private f32 scratch
+    // [32][RS] through which first da of this tile, then the V column are transposed
+    float* scr = waves_s + wave * G::WAVE_F;
+    pv_u32x4* vpost = reinterpret_cast<pv_u32x4*>(waves_s);  // [4 w][2 i][3 term][64 lanes]
     pv_u32x4* dpost = reinterpret_cast<pv_u32x4*>(waves_s + NW * G::WAVE_F);  // [T][2 q][3 term][64 lanes]
     float* dbias_s = waves_s + NW * G::WAVE_F + G::POST_F;                    // [2][NW][32]
     const int nrows = st->nrows;
@@ -1911,6 +1945,11 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3b(const float* __restrict__ V,
         for (int r = 0; r < 16; ++r) dg[w][r] = 0.f;
     float lossacc = 0.f;
 
+#ifdef PV_DEC3_PROF
+    unsigned long long d3acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d3last = __builtin_amdgcn_s_memtime();
+    const unsigned long long d3rt0 = __builtin_amdgcn_s_memrealtime();
+    int d3visits = 0;
+#endif
     for (int it = 0; blk < nblk; ++it) {
         const int nb = subtile_of(it + 1) < nblk ? subtile_of(it + 1) : blk;  // past the end: a harmless re-read
         const int l = blk * 32 + c;
@@ -1931,34 +1970,66 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3b(const float* __restrict__ V,
         const int64_t go = (int64_t)blk * (4 * 256) + (t * 4) * 64 + lane;  // gradient dumps are plain tiles
         const uint64_t xs = xw >> (8 * h);
         const uint32_t lo = (uint32_t)xs, hi = (uint32_t)(xs >> 32);
+        PV_D3(0);
         // (1) logits of tile t on the bf16 pipe; the next visit's V is requested between the instructions
         f32x16 a;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = 0.f;
+        // The eight V values of group s + 1 are cut into their terms between the six matrix instructions of group s = (w, i), one
+        // stage of pv_cut_stage behind each, held in place by scheduling barriers.  This does NOT overlap VALU and matrix work:
+        // a wave's own VALU instructions do not issue in the shadow of its own matrix instruction (tools/mfma_valu_probe.hip: 33.7
+        // cycles per v_mfma_f32_32x32x16_bf16 alone, + 2.2 per independent VALU instruction behind it, with one or two accumulator
+        // chains), and this kernel runs one wave per SIMD.  What the staging buys is that operand reads and requests are never
+        // waited for: 3900 -> 2850 cycles per visit for the phase (1536 of matrix pipe + ~350 VALU instructions).
+        pv_u32x4 bh[2], bm[2], bl[2];
+        PvCut3 ct;
+        auto cut_load = [&](int s_) {
+            const int w = s_ >> 1, i = s_ & 1;
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
+            for (int j = 0; j < 8; ++j) ct.x[j] = vv[w][2 * i + (j >> 2)][j & 3];
+        };
+        cut_load(0);
+        pv_cut_stage<0>(ct, bh[0], bm[0], bl[0]);
+        pv_cut_stage<1>(ct, bh[0], bm[0], bl[0]);
+        pv_cut_stage<2>(ct, bh[0], bm[0], bl[0]);
+        pv_cut_stage<3>(ct, bh[0], bm[0], bl[0]);
+        pv_cut_stage<4>(ct, bh[0], bm[0], bl[0]);
+        pv_cut_stage<5>(ct, bh[0], bm[0], bl[0]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                vn[w][2 * i] = __builtin_nontemporal_load(tVn + (w * 4 + 2 * i) * 64);
-                vn[w][2 * i + 1] = __builtin_nontemporal_load(tVn + (w * 4 + 2 * i + 1) * 64);
-                const float x[8] = {vv[w][2 * i][0], vv[w][2 * i][1], vv[w][2 * i][2], vv[w][2 * i][3],
-                                    vv[w][2 * i + 1][0], vv[w][2 * i + 1][1], vv[w][2 * i + 1][2], vv[w][2 * i + 1][3]};
-                pv_u32x4 bh, bm, bl;
-                pv_split3(x, bh, bm, bl);
-                const pv_u32x4* src = gop + (((t * 4 + w) * 2 + i) * 3) * 64 + lane;
-                const pv_u32x4 ah = src[0], am = src[64], al = src[128];
-                a = pv_mfma_bf16(al, bh, a);
-                a = pv_mfma_bf16(ah, bl, a);
-                a = pv_mfma_bf16(am, bm, a);
-                a = pv_mfma_bf16(am, bh, a);
-                a = pv_mfma_bf16(ah, bm, a);
-                a = pv_mfma_bf16(ah, bh, a);
-            }
+        for (int s_ = 0; s_ < 8; ++s_) {
+            const int w = s_ >> 1, i = s_ & 1, cur = s_ & 1, nxt = cur ^ 1;
+            const pv_u32x4* src = gop + (((t * 4 + w) * 2 + i) * 3) * 64 + lane;
+            const pv_u32x4 ah = src[0], am = src[64], al = src[128];
+            vn[w][2 * i] = __builtin_nontemporal_load(tVn + (w * 4 + 2 * i) * 64);
+            vn[w][2 * i + 1] = __builtin_nontemporal_load(tVn + (w * 4 + 2 * i + 1) * 64);
+            if (s_ + 1 < 8) cut_load(s_ + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            a = pv_mfma_bf16(al, bh[cur], a);
+            if (s_ + 1 < 8) pv_cut_stage<0>(ct, bh[nxt], bm[nxt], bl[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+            a = pv_mfma_bf16(ah, bl[cur], a);
+            if (s_ + 1 < 8) pv_cut_stage<1>(ct, bh[nxt], bm[nxt], bl[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+            a = pv_mfma_bf16(am, bm[cur], a);
+            if (s_ + 1 < 8) pv_cut_stage<2>(ct, bh[nxt], bm[nxt], bl[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+            a = pv_mfma_bf16(am, bh[cur], a);
+            if (s_ + 1 < 8) pv_cut_stage<3>(ct, bh[nxt], bm[nxt], bl[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+            a = pv_mfma_bf16(ah, bm[cur], a);
+            if (s_ + 1 < 8) pv_cut_stage<4>(ct, bh[nxt], bm[nxt], bl[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+            a = pv_mfma_bf16(ah, bh[cur], a);
+            if (s_ + 1 < 8) pv_cut_stage<5>(ct, bh[nxt], bm[nxt], bl[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        PV_D3(1);
         // (2) sigmoid / BCE / dlogits of tile t
         float dbias = 0.f;
         pv_sigmoid_bce(bce_probs, (blk * 32 + 32 <= L) && (32 * t + 32 <= nrows), true, a, bias, lo, hi, h, 32 * t, nrows, lvalid,
                        inv_b, lossacc, dbias);
         dbias += __shfl_xor(dbias, 32);
+        PV_D3(2);
         // everything the other waves read of last visit's posts has been read (their arrival at B) before it is overwritten
         sync_ok &= pv_block_wait(&sync_b, T * it);
         float* dbias_v = dbias_s + (it & 1) * NW * 32;
@@ -1975,14 +2046,55 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3b(const float* __restrict__ V,
             dst[64] = dm;
             dst[128] = dl;
         }
+        // da^T of this tile as the A operand of product (3): lane (b, kg) of instruction i holds SNPs 16 i + 8 kg + j.  The
+        // accumulator has the SNP on the lane: through the scratch, [b][l] written by rows of registers, read back 8 SNPs a lane
+        pv_u32x4 ath[2], atm[2], atl[2];
+        constexpr int RS = G::RS;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dt[PV_ROW(r, h) * 33 + c] = a[r];
+        for (int r = 0; r < 16; ++r) scr[PV_ROW(r, h) * RS + c] = a[r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        {
+            f32x4 xa[2][2];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if (w != t) continue;  // wave-uniform
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) vtc[PV_ROW(r, h) * 33 + c] = vv[w][r >> 2][r & 3];
+                for (int p = 0; p < 2; ++p) xa[i][p] = *reinterpret_cast<const f32x4*>(scr + c * RS + 16 * i + 8 * h + 4 * p);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            // ... then V^T of block column t the same way (same scratch), cut into its terms
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (w != t) continue;  // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) scr[PV_ROW(r, h) * RS + c] = vv[w][r >> 2][r & 3];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float x[8] = {xa[i][0][0], xa[i][0][1], xa[i][0][2], xa[i][0][3], xa[i][1][0], xa[i][1][1], xa[i][1][2], xa[i][1][3]};
+                pv_split3(x, ath[i], atm[i], atl[i]);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            f32x4 xv[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) xv[i][p] = *reinterpret_cast<const f32x4*>(scr + c * RS + 16 * i + 8 * h + 4 * p);
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // every read of the scratch is back before the terms overwrite it
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float x[8] = {xv[i][0][0], xv[i][0][1], xv[i][0][2], xv[i][0][3], xv[i][1][0], xv[i][1][1], xv[i][1][2], xv[i][1][3]};
+                pv_u32x4 vh, vm, vl;
+                pv_split3(x, vh, vm, vl);
+                pv_u32x4* dst = vpost + ((t * 2 + i) * 3) * 64 + lane;
+                dst[0] = vh;
+                dst[64] = vm;
+                dst[128] = vl;
+            }
         }
+        PV_D3(3);
         pv_block_arrive(&sync_c, lane);
         // what the update of block column t reads besides V: the moments (Adam), the dump (accumulate variants)
 #pragma unroll
@@ -1996,14 +2108,7 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3b(const float* __restrict__ V,
             }
         }
         sync_ok &= pv_block_wait(&sync_c, T * (it + 1));
-        // (3) dg[b][unit] += sum_l da[b][l] V[unit][l] (fp32 instruction): A = da^T of this tile, B = V^T column w (wave w's)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float* vt = waves_s + w * G::WAVE_F + 32 * 33;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dg[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(dt[c * 33 + PV_ROW(r, h)], vt[c * 33 + PV_ROW(r, h)], dg[w], 0, 0, 0);
-        }
+        PV_D3(4);
         // (4) dV of block column t over all 128 rows on the bf16 pipe: tiles in order, one accumulator
         f32x16 dv;
 #pragma unroll
@@ -2021,34 +2126,75 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3b(const float* __restrict__ V,
                 dv = pv_mfma_bf16(gth[t2][q], dm, dv);
                 dv = pv_mfma_bf16(gth[t2][q], dh, dv);
             }
-        // Adam on block column t (or the gradient dump)
+        PV_D3(5);
+        // (3) dg[b][unit] += sum_l da[b][l] V[unit][l] on the bf16 pipe: A = the terms of da^T (registers), B = the terms of V^T of
+        //     block column w (wave w's post).  The update of block column t sits in the same basic block (the column is picked
+        //     with selects, not with a branch on t), so that its stores and the waits for its moments are scheduled among the
+        //     matrix instructions; the arithmetic itself does not hide behind them (see product (1)).
+        f32x4 wsel[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if (w != t) continue;  // wave-uniform: vv[t] without a dynamic register index
+        for (int q = 0; q < 4; ++q) {
+            wsel[q] = vv[0][q];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 gsum = {dv[4 * q], dv[4 * q + 1], dv[4 * q + 2], dv[4 * q + 3]};
-                const int off = (w * 4 + q) * 64;
-                if (MODE == PV_MODE_GRAD) {
-                    if (acc_grads) gsum += gq[q];
-                    __builtin_nontemporal_store(gsum, reinterpret_cast<f32x4*>(mV2) + go + q * 64);
-                    continue;
-                }
-                if (MODE == PV_MODE_TRAIN_ACC) gsum += gq[q];
-                f32x4 wq = vv[w][q], m4 = mq[q], v4 = vq[q];
+            for (int w = 1; w < 4; ++w) wsel[q] = (t == w) ? vv[w][q] : wsel[q];
+        }
+        f32x4 oW[4], oM[4], oV[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float w_ = wq[e], m_ = m4[e], v_ = v4[e];
-                    pv_adam(w_, m_, v_, gsum[e], alpha, adam);
-                    wq[e] = w_;
-                    m4[e] = m_;
-                    v4[e] = v_;
-                }
-                __builtin_nontemporal_store(wq, reinterpret_cast<f32x4*>(V2) + tb + off);
-                __builtin_nontemporal_store(m4, reinterpret_cast<f32x4*>(mV2) + tb + off);
-                __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(vV2) + tb + off);
+        for (int q = 0; q < 4; ++q) {
+            f32x4 gsum = {dv[4 * q], dv[4 * q + 1], dv[4 * q + 2], dv[4 * q + 3]};
+            if (MODE == PV_MODE_GRAD) {
+                if (acc_grads) gsum += gq[q];
+                oM[q] = gsum;
+                continue;
+            }
+            if (MODE == PV_MODE_TRAIN_ACC) gsum += gq[q];
+            f32x4 wq = wsel[q], m4 = mq[q], v4 = vq[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float w_ = wq[e], m_ = m4[e], v_ = v4[e];
+                pv_adam(w_, m_, v_, gsum[e], alpha, adam);
+                wq[e] = w_;
+                m4[e] = m_;
+                v4[e] = v_;
+            }
+            oW[q] = wq;
+            oM[q] = m4;
+            oV[q] = v4;
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const pv_u32x4* src = vpost + ((w * 2 + i) * 3) * 64 + lane;
+                const pv_u32x4 vh = src[0], vm = src[64], vl = src[128];
+                dg[w] = pv_mfma_bf16(atl[i], vh, dg[w]);
+                dg[w] = pv_mfma_bf16(ath[i], vl, dg[w]);
+                dg[w] = pv_mfma_bf16(atm[i], vm, dg[w]);
+                dg[w] = pv_mfma_bf16(atm[i], vh, dg[w]);
+                dg[w] = pv_mfma_bf16(ath[i], vm, dg[w]);
+                dg[w] = pv_mfma_bf16(ath[i], vh, dg[w]);
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int off = (t * 4 + q) * 64;
+            if (MODE == PV_MODE_GRAD) {
+                __builtin_nontemporal_store(oM[q], reinterpret_cast<f32x4*>(mV2) + go + q * 64);
+            } else {
+                __builtin_nontemporal_store(oW[q], reinterpret_cast<f32x4*>(V2) + tb + off);
+                __builtin_nontemporal_store(oM[q], reinterpret_cast<f32x4*>(mV2) + tb + off);
+                __builtin_nontemporal_store(oV[q], reinterpret_cast<f32x4*>(vV2) + tb + off);
             }
         }
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
+        }
+        PV_D3(6);
         if (t == 0 && h == 0 && lvalid) {  // the output bias: sum of the tiles' parts, in tile order
             float gb = dbias_v[c];
 #pragma unroll
@@ -2064,6 +2210,7 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3b(const float* __restrict__ V,
                 vC[l] = cv;
             }
         }
+        PV_D3(8);
         pv_block_arrive(&sync_b, lane);
 #pragma unroll
         for (int w = 0; w < 4; ++w)
@@ -2072,7 +2219,18 @@ __global__ __launch_bounds__(256, 1) void pvk_dec3b(const float* __restrict__ V,
         xw = xw_n;
         bias = bias_n;
         blk = subtile_of(it + 1);
+        PV_D3(9);
+#ifdef PV_DEC3_PROF
+        ++d3visits;
+#endif
     }
+#ifdef PV_DEC3_PROF
+    if (tid == 0 && blockIdx.x < 256) {
+        for (int i = 0; i < 10; ++i) pv_wtrace_buf[blockIdx.x * 12 + i] = d3acc[i];
+        pv_wtrace_buf[blockIdx.x * 12 + 10] = d3visits;
+        pv_wtrace_buf[blockIdx.x * 12 + 11] = __builtin_amdgcn_s_memrealtime() - d3rt0;
+    }
+#endif
     // ---- per-workgroup reductions (fixed order) ----
     __syncthreads();
     float* red = smem;  // [NW][4][16][64], then [NW] loss

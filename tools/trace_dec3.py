@@ -22,6 +22,8 @@ a = np.array(buf[:256 * 12], dtype=np.int64).reshape(256, 12)
 a = a[a[:, 10] > 0]
 per = a[:, :10] / a[:, 10:11]
 names = ["requests", "logits", "sigmoid", "waitB+stage", "sync C", "dg", "dV+post", "sync A", "update", "rotate"]
+if B > 64 and not os.environ.get("PVAE_NO_DEC3B"):  # pvk_dec3b's stamps
+    names = ["requests", "logits", "sigmoid", "waitB+posts", "sync C", "dV", "dg", "-", "update", "rotate"]
 print(f"L={L} B={B}: {len(a)} workgroups, visits per wave {a[:, 10].mean():.1f}; cycles per visit (mean / p10 / p90 over workgroups)")
 for i, nm in enumerate(names):
     print(f"  {nm:12s} {per[:, i].mean():8.0f} {np.percentile(per[:, i], 10):8.0f} {np.percentile(per[:, i], 90):8.0f}")
