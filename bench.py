@@ -212,7 +212,7 @@ def main():
     run(batches(20))
     barrier()
     kern = {}
-    for name in ("gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd", "xch0", "xch1"):
+    for name in ("gather", "enc_fwd", "narrow_fwd", "dec", "reduce", "narrow_bwd", "enc_bwd", "xch0", "xch1"):
         ms, n = eng.get_timing(name)
         kern[name] = (ms, n)
     kern["dec"] = dec_timed
@@ -300,7 +300,8 @@ def main():
                          "algorithmic_bytes_per_launch": algo["dec"],
                          "avg_launch_ms": kernels.get("dec", {}).get("ms")},
             "kernels": kernels,
-            "kernels_note": "dec: HIP events over the timed repetitions; the others (and xch0 / xch1, the two all-reduces of a "
+            "kernels_note": "dec: HIP events around the decoder kernel alone, over the timed repetitions (reduce = the fixed-order sum "
+                            "of its partial tiles, a launch of its own); the others (and xch0 / xch1, the two all-reduces of a "
                             "step on the engine-owned communicator): a separate untimed pass of 20 steps",
             "comm": step_engine.comm_report() if sharded else None,
             "epochs_per_sec": 1e3 / epoch_ms if epoch_ms else 1.0 / ((st_tr * ms_per_step + st_va * val_ms) * 1e-3),

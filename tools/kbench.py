@@ -41,7 +41,7 @@ Wp = (W + 31) // 32 * 32 if W <= 128 else (256 if W <= 256 else 512)
 algo = {"dec": 24 * L * Wp + 32 * L, "enc_fwd": 4 * L * Wp + 8 * L, "enc_bwd": 24 * L * Wp + 8 * L}
 print(f"{name} B={B}: {dt / steps * 1e3:.3f} ms/step  {steps * B / dt:.0f} samples/s  loss {loss:.3f}")
 tot = 0
-for k in ("gather", "enc_fwd", "narrow_fwd", "dec", "dec_upd", "narrow_bwd", "enc_bwd"):
+for k in ("gather", "enc_fwd", "narrow_fwd", "dec", "dec_upd", "reduce", "narrow_bwd", "enc_bwd"):
     ms, n = e.get_timing(k)
     if n:
         a = ms / n

@@ -38,7 +38,7 @@ def run(L, W, D, timing):
         best = dt if best is None else min(best, dt)
     kern = {}
     if timing:
-        for k in ("gather", "enc_fwd", "narrow_fwd", "dec", "narrow_bwd", "enc_bwd"):
+        for k in ("gather", "enc_fwd", "narrow_fwd", "dec", "reduce", "narrow_bwd", "enc_bwd"):
             ms, n = e.get_timing(k)
             if n:
                 kern[k] = round(ms / n * 1e3, 2)
