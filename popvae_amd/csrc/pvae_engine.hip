@@ -1832,19 +1832,29 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
         HIPCHK(hipMemcpyAsync(e->d_rows + n_train, val_rows, (size_t)n_val * sizeof(int), hipMemcpyHostToDevice, e->stream));
     bool fwd_done = false;
     const int tp = (B + 31) / 32;  // 32-row tiles per batch
+    // batches above 32 rows: every loss slot of the epoch starts at zero (tiles a short batch does not reach stay there) -- one
+    // fill per epoch, and the per-step scalars share a launch with the first noise draw of the step (three launch slots per
+    // step, ~15 us, were a fill, pvk_step_begin and pvk_gen_eps)
+    if (tp > 1) HIPCHK(hipMemsetAsync(e->d_loss, 0, (size_t)3 * tp * (st_tr + st_va) * sizeof(float), e->stream));
     for (int phase = 0; phase < 2 && tp > 1; ++phase) {
         // batches above 32 rows: tiles with accumulated gradients, one Adam update per batch
         const int steps = phase == 0 ? st_tr : st_va, nt = phase == 0 ? n_train : n_val, base = phase == 0 ? 0 : n_train;
         for (int s = 0; s < steps; ++s) {
             const int nb = std::min(B, nt - s * B);
             float* slot = e->d_loss + 3 * (size_t)((phase == 0 ? 0 : st_tr) + s) * tp;
-            HIPCHK(hipMemsetAsync(slot, 0, (size_t)3 * tp * sizeof(float), e->stream));
-            hipLaunchKernelGGL(pvk_step_begin, dim3(1), dim3(64), 0, e->stream, e->st, (const int*)nullptr, nb, B, 0, phase == 0 ? 1 : 0,
-                               e->adam.b1, e->adam.b2);
+            bool begun = false;  // the step's scalars are written by its first noise launch
+            auto begin_eps = [&](int n_eps) {
+                if (!begun)
+                    hipLaunchKernelGGL(pvk_step_begin_eps, dim3(1), dim3(1024), 0, e->stream, e->st, (const int*)nullptr, nb, B, 0,
+                                       phase == 0 ? 1 : 0, e->adam.b1, e->adam.b2, e->eps, n_eps, e->cfg.seed, e->d_counter);
+                else
+                    hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, n_eps, e->cfg.seed, e->d_counter);
+                begun = true;
+            };
             if (phase == 0 && e->T > 1 && nb > 32) {  // the whole batch in one weight pass, or one pass per 32 T rows
                 const int R = 32 * e->T, nc = (nb + R - 1) / R;
                 for (int c = 0; c < nc; ++c) {
-                    hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, R * e->K, e->cfg.seed, e->d_counter);
+                    begin_eps(R * e->K);
                     if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
                     if (nc == 1) rc = multi_tile_train(e, base + s * B, slot);
                     else rc = run_chunk(e, base + s * B + R * c, std::min(R, nb - R * c), nb, c, c == nc - 1, slot + 3 * c);
@@ -1855,14 +1865,14 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
             if (phase == 1 && e->T > 1 && nb > 32 && e->fused_narrow) {  // validation: one read of the wide weights per 32 T rows
                 const int R = 32 * e->T, nc = (nb + R - 1) / R;
                 for (int c = 0; c < nc; ++c) {
-                    hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, R * e->K, e->cfg.seed, e->d_counter);
+                    begin_eps(R * e->K);
                     if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
                     if ((rc = multi_tile_eval(e, base + s * B + R * c, std::min(R, nb - R * c), nb, slot + 3 * c))) return rc;
                 }
                 continue;
             }
             for (int t = 0; t * 32 < nb; ++t) {
-                hipLaunchKernelGGL(pvk_gen_eps, dim3(1), dim3(1024), 0, e->stream, e->eps, 32 * e->K, e->cfg.seed, e->d_counter);
+                begin_eps(32 * e->K);
                 if ((rc = launch_check(e, "step_begin/gen_eps"))) return rc;
                 // a short last batch of at most 32 rows is ONE tile: a plain train step (TRAIN_ACC would add the gradient
                 // dump the previous batch's tiles left behind, or find none at all when n_train <= 32 < batch_size)
