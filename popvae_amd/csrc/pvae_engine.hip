@@ -140,6 +140,15 @@ struct pvae_engine {
     // (profiles/r03_exp_xrn_pmc_traffic_C4.json) but not its time (546-547 us against 548), and the head writes 8 MB more per
     // step at 1M SNPs (8.2 -> 11.7 us): a net loss of ~2 us per step, so it is opt-in (PVAE_XRN=1).
     bool use_xrn = false;
+    // Opt-in (PVAE_GATHER_AHEAD=1): the next batch is gathered by a launch of its own (pvk_gather_next) on `gstream`, beside the
+    // narrow forward chain of the current step, where HBM idles; the head keeps its partial sums, scalars and noise and the fused
+    // forward reads the compact words.  Bit-identical, and measured SLOWER (C2 0.184 against 0.175 ms/step, C4 1.171 against
+    // 1.158): each of the two cross-stream event waits of a step opens a ~6 us bubble on the waiting stream (rocprofv3 timeline,
+    // tools/gpu_ga.sh) -- more than the ~5 us the head saves.  The same bubbles are part of what the two-launch decoder pass loses.
+    bool gather_ahead = false;
+    hipStream_t gstream = nullptr;
+    hipEvent_t ev_pre = nullptr, ev_gather = nullptr;
+    bool gather_pending = false;  // `stream` has not waited for the gather in flight on `gstream` yet
     bool narrow_pack_dirty = true;  // the operand-order copies lag behind the Keras-layout kernels
     PvFwdOp* d_fwd_ops = nullptr;
     PvBwdOp *d_bwd_ops = nullptr, *d_bwd_ops_grad = nullptr;
@@ -668,6 +677,17 @@ int join_side(pvae_engine* e) {
     HIPCHK(hipStreamWaitEvent(e->stream, e->ev_upd, 0));
     return 0;
 }
+int join_gather(pvae_engine* e) {  // `stream` waits for the next-batch gather in flight on `gstream`
+    if (!e->gather_pending) return 0;
+    e->gather_pending = false;
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_gather, 0));
+    return 0;
+}
+struct GatherScope {  // leaves the epoch loop with the gather stream joined, whatever the exit
+    pvae_engine* e;
+    explicit GatherScope(pvae_engine* e_) : e(e_) {}
+    ~GatherScope() { join_gather(e); }
+};
 struct SplitScope {  // the epoch loop's plain training steps; leaves with the side stream joined, whatever the exit
     pvae_engine* e;
     explicit SplitScope(pvae_engine* e_, bool on) : e(e_) { e->split_now = on; }
@@ -1577,6 +1597,12 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     e->fuse_fwd = !getenv("PVAE_NO_FUSE_FWD");
     e->dec3b = !getenv("PVAE_NO_DEC3B");
     e->use_xrn = getenv("PVAE_XRN") != nullptr;
+    e->gather_ahead = e->fuse_fwd && !e->use_xrn && getenv("PVAE_GATHER_AHEAD") != nullptr;
+    if (e->gather_ahead) {
+        HK(hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking));
+        HK(hipEventCreateWithFlags(&e->ev_pre, hipEventDisableTiming));
+        HK(hipEventCreateWithFlags(&e->ev_gather, hipEventDisableTiming));
+    }
     e->dgpart_cap = std::max((int64_t)std::max(e->dec_wgs, e->dec2_wgs) * 32 * e->Wp, (int64_t)e->dec3_wgs * 32 * e->T * e->Wp);
     CK(allocf(e, &e->dgpart, e->dgpart_cap));
     // one BCE sum per workgroup of whichever decoder kernel runs; pvk_dec_eval_mt<T, 1> leaves one per workgroup AND row tile
@@ -1637,6 +1663,9 @@ int pvae_destroy(pvae_engine* e) {
     hipSetDevice(e->dev);
     if (e->own_stream) hipStreamSynchronize(e->own_stream);
     if (e->side) { hipStreamSynchronize(e->side); hipStreamDestroy(e->side); }
+    if (e->gstream) { hipStreamSynchronize(e->gstream); hipStreamDestroy(e->gstream); }
+    if (e->ev_pre) hipEventDestroy(e->ev_pre);
+    if (e->ev_gather) hipEventDestroy(e->ev_gather);
     if (e->ev_da) hipEventDestroy(e->ev_da);
     if (e->ev_upd) hipEventDestroy(e->ev_upd);
     pvae_comm_destroy(e);
@@ -1906,6 +1935,7 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
         HIPCHK(hipStreamSynchronize(e->stream));  // nt is a stack variable
         const int base = phase == 0 ? 0 : n_train;
         SplitScope split(e, phase == 0 && e->split_dec);
+        GatherScope gscope(e);
         for (int s = 0; s < steps; ++s) {
             if ((rc = join_side(e))) return rc;
             // the first-layer forward of the NEXT batch rides on this step's wide encoder backward
@@ -1922,8 +1952,19 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
             // nothing left to gather -- one gather per step either way, and the fused forward reads a compact array.
             const int nred = fwd_done ? PV_REDUCE_GRID(32 * e->Wp) : 0, ngb = ((e->nblk + 1) / 2 + 3) / 4;
             uint64_t *xt_cur = xt_par ? e->Xt2 : e->Xt, *xt_next = xt_par ? e->Xt : e->Xt2;
-            const bool pre = fuse && e->use_xrn;  // gather the next batch now
-            const int ngather = xt_ready ? 0 : ngb, ngather_next = pre ? ngb : 0;
+            const bool ahead = fuse && e->gather_ahead;  // ... by a launch of its own on the gather stream
+            const bool pre = fuse && (e->use_xrn || ahead);  // the next batch is gathered during this step
+            const int ngather = xt_ready ? 0 : ngb, ngather_next = pre && !ahead ? ngb : 0;
+            if (ahead) {
+                // Xt_next and Xrn were last read by the previous step's kernels: the gather may start once those are done, i.e.
+                // behind everything enqueued on `stream` so far -- and then runs beside this step's head and forward chain
+                HIPCHK(hipEventRecord(e->ev_pre, e->stream));
+                HIPCHK(hipStreamWaitEvent(e->gstream, e->ev_pre, 0));
+                hipLaunchKernelGGL(pvk_gather_next, dim3(ngb), dim3(256), 0, e->gstream, (const uint8_t*)e->geno, e->row_bytes,
+                                   (const int*)e->d_rows, next_off, next_n, e->nblk, xt_next, e->Xrn);
+                HIPCHK(hipEventRecord(e->ev_gather, e->gstream));
+                e->gather_pending = true;
+            }
             hipLaunchKernelGGL(pvk_step_begin_gather, dim3(nred + ngather + ngather_next + 1), dim3(256), 0, e->stream, e->st,
                                (const int*)e->d_ntotal, B, s, phase == 0 ? 1 : 0, e->adam.b1, e->adam.b2, e->eps, 32 * e->K,
                                e->cfg.seed, e->d_counter, e->geno, e->row_bytes, (const int*)e->d_rows, base + s * B, e->nblk, xt_cur,
@@ -1938,6 +1979,7 @@ int pvae_train_epoch(pvae_engine* e, const int32_t* perm, int32_t n_train, const
             if ((rc = shard_allreduce(e, 0))) return rc;
             if ((rc = stage_b(e, phase == 0 ? 0 : 1))) return rc;
             if ((rc = shard_allreduce(e, 1))) return rc;
+            if ((rc = join_gather(e))) return rc;  // the fused forward of the wide encoder backward reads the next batch's words
             if ((rc = stage_c(e, phase == 0 ? 0 : 1, e->d_loss + 3 * ((phase == 0 ? 0 : st_tr) + s), fuse, next_off, next_n, xrn)))
                 return rc;
             fwd_done = fuse;

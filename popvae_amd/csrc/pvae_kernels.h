@@ -2981,6 +2981,14 @@ __global__ __launch_bounds__(256) void pvk_step_begin_gather(PvStep* st, const i
 }
 
 
+// The NEXT batch of the epoch loop, gathered on a second stream while the narrow forward chain runs (HBM idles there): the
+// transposed copy into Xt_next and the compact words into Xrn (operand of the forward fused into pvk_enc_bwd).  grid = ngb blocks.
+__global__ __launch_bounds__(256) void pvk_gather_next(const uint8_t* __restrict__ geno, int64_t row_bytes,
+                                                       const int* __restrict__ rows, int next_off, int next_n, int nblk,
+                                                       uint64_t* __restrict__ Xt_next, uint64_t* __restrict__ Xrn) {
+    pv_gather_block(geno, row_bytes, rows, next_n, next_off, nblk, Xt_next, Xrn, (int)blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Layout conversion between Keras row-major tensors and the fragment-native tiled layout.
 // kind 0: encoder W1 (Keras [L][W]);  kind 1: decoder V (Keras [W][L]).  dir 0: keras->tiled, 1: tiled->keras.

@@ -1,6 +1,7 @@
 """The engine's opt-in paths (environment switches read by pvae_create) must give the step they replace:
    PVAE_SPLIT_DEC=1  the decoder pass as two launches of pvk_dec2<.., PART>, the second on a CU-masked side stream -- bit-identical;
    PVAE_XRN=1        the step head gathers the NEXT batch into compact words for the forward fused into pvk_enc_bwd -- bit-identical;
+   PVAE_GATHER_AHEAD=1  the next batch is gathered by a launch of its own on a second stream, beside the forward chain -- bit-identical;
    PVAE_NO_DEC3B=1   four row tiles through the fp32 decoder training kernel instead of pvk_dec3b -- same result to 1e-4 (the
                      two kernels sum in different orders).
 Measured slower or equal, kept for A/B comparisons; these tests keep them working."""
@@ -50,7 +51,8 @@ def _run(env, N, L, W, D, B, epochs, lr=1e-4):
     return np.array(hist, np.float64), w, m
 
 
-@pytest.mark.parametrize("env", [{"PVAE_SPLIT_DEC": "1"}, {"PVAE_SPLIT_DEC": "1", "PVAE_SPLIT_RESERVE": "1"}, {"PVAE_XRN": "1"}])
+@pytest.mark.parametrize("env", [{"PVAE_SPLIT_DEC": "1"}, {"PVAE_SPLIT_DEC": "1", "PVAE_SPLIT_RESERVE": "1"}, {"PVAE_XRN": "1"},
+                                 {"PVAE_GATHER_AHEAD": "1"}, {"PVAE_GATHER_AHEAD": "1", "PVAE_SPLIT_DEC": "1"}])
 @pytest.mark.parametrize("L,W", [(5000, 128), (2077, 64)])
 def test_opt_in_epoch_loops_are_bit_identical(env, L, W):
     ref = _run({}, 150, L, W, 3, 32, 3)
