@@ -43,7 +43,11 @@ def test_multi_tile_equals_tile_path(seed, monkeypatch):
             monkeypatch.setenv("PVAE_NO_MULTITILE", "1")
         else:
             monkeypatch.delenv("PVAE_NO_MULTITILE", raising=False)
-        e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=B, seed=3)
+        # lr = 1e-5: this is a differential test of kernels, not of training dynamics.  At Keras' 1e-3 some of these shapes
+        # are in the blow-up regime on the second step (loss 6e3 -> 3e5), where the 1e-7 by which the two paths' first steps differ
+        # -- Adam turns rounding noise into steps of up to lr where the gradient is ~0 -- moves a moment by up to 3e-4
+        # (2 of 80 cases, tools/fuzz_one.py; at 1e-5 every tensor of those cases agrees to 1e-6 after both steps)
+        e = engine.Engine(n_snps=L, width=W, depth=D, latent_dim=K, batch_size=B, seed=3, lr=1e-5)
         e.load_genotypes(packed)
         e.init_weights(11)
         res = []
@@ -60,8 +64,8 @@ def test_multi_tile_equals_tile_path(seed, monkeypatch):
     for i, (a, b) in enumerate(zip(ma, mb)):
         assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-30), (tag, "moment", i, np.abs(a - b).max(), np.abs(b).max())
     for i, (a, b) in enumerate(zip(wa, wb)):
-        # two Adam steps of lr = 1e-3: the bulk of the entries agree to float32 rounding of the update
-        assert np.median(np.abs(a - b)) <= 1e-7 and np.abs(a - b).max() <= 2.1e-3, (tag, i, np.abs(a - b).max())
+        # two Adam steps of lr = 1e-5: the bulk of the entries agree to float32 rounding of the update
+        assert np.median(np.abs(a - b)) <= 1e-7 and np.abs(a - b).max() <= 2.1e-5, (tag, i, np.abs(a - b).max())
 
 
 def _case_epoch(seed):
