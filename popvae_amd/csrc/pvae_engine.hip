@@ -126,6 +126,7 @@ struct pvae_engine {
     // pvk_enc_bwd <.., T>, pvk_dec3<T> and 2 T chain workers; activation buffers hold 32 T rows.  T == 1: off.
     int T = 1;
     int dec3_wgs = 0;          // grid of pvk_dec3<T> (one workgroup per CU, 4 / T subtiles per iteration)
+    bool dense16 = true;       // widths 256 / 512: pvk_dense_fwd16 for the hidden layers (PVAE_NO_DENSE16=1: pvk_dense_fwd)
     bool dec3b = true;         // T = 4: pvk_dec3b (logits and dV on the bf16 matrix pipe) instead of pvk_dec3<4>
     int dece_mt_wgs = 0;       // grid of pvk_dec_eval_mt<T> (two workgroups per CU: the T g tiles are 16.5 T KB of LDS)
     int encf_mt_wgs = 0;       // grid of pvk_enc_fwd<4, T> (T > 1: no fused forward to match, two workgroups on every CU) = its partial tiles
@@ -359,6 +360,10 @@ hipError_t allow_lds(Kern k, size_t bytes) {
 int setup_kernel_attrs(pvae_engine* e) {
     int maxK = std::max(e->Wp, std::max(e->Kh, e->Kz));
     HIPCHK(allow_lds(pvk_dense_fwd, lds_dense_fwd(maxK)));
+    HIPCHK(allow_lds(pvk_dense_fwd16<512>, (size_t)(32 * (512 + 4) + 4096) * 4));
+    HIPCHK(allow_lds(pvk_dense_fwd16<256>, (size_t)(32 * (256 + 4) + 4096) * 4));
+    HIPCHK(allow_lds(pvk_dense_bwd16<512>, (size_t)(32 * (512 + 4) + 4096) * 4));
+    HIPCHK(allow_lds(pvk_dense_bwd16<256>, (size_t)(32 * (256 + 4) + 4096) * 4));
     HIPCHK(allow_lds(pvk_dense_bwd, lds_dense_bwd(maxK)));
     HIPCHK(allow_lds(pvk_narrow_fwd, pvn_lds_fwd()));
     HIPCHK(allow_lds(pvk_narrow_bwd<PV_MODE_TRAIN>, pvn_lds_bwd()));
@@ -506,14 +511,40 @@ int shard_allreduce(pvae_engine* e, int which, int rows = 32) {
 int run_dense_fwd(pvae_engine* e, const Dense& d, const float* in, float* out, const float* in_bias = nullptr,
                   float* in_act = nullptr, PvRepFwd rp = PvRepFwd{}) {
     if (rp.z && d.nout != 32) return set_err(e, -6, "sampling tail on a layer of %d outputs", d.nout);
+    if (!rp.z && e->dense16 && (d.kin == 256 || d.kin == 512) && d.nout % 16 == 0) {  // hidden layers at widths 256 / 512
+        const size_t lds = (size_t)(32 * (d.kin + 4) + 4096) * 4;
+        if (d.kin == 512)
+            hipLaunchKernelGGL(pvk_dense_fwd16<512>, dim3(d.nout / 16), dim3(512), lds, e->stream, in, (const float*)d.W.w,
+                               (const float*)d.B.w, d.nout, d.act, out, in_bias, in_act);
+        else
+            hipLaunchKernelGGL(pvk_dense_fwd16<256>, dim3(d.nout / 16), dim3(512), lds, e->stream, in, (const float*)d.W.w,
+                               (const float*)d.B.w, d.nout, d.act, out, in_bias, in_act);
+        return launch_check(e, "dense_fwd16");
+    }
     hipLaunchKernelGGL(pvk_dense_fwd, dim3(d.nout / 32), dim3(256), lds_dense_fwd(d.kin), e->stream, in, d.kin, d.W.w,
                        d.B.w, d.nout, d.act, out, in_bias, in_act, rp);
     return launch_check(e, "dense_fwd");
 }
 
+// hidden layers at widths 256 / 512 take pvk_dense_bwd16 (16 input units per workgroup)
+bool dense16_bwd_ok(const pvae_engine* e, const Dense& d) {
+    return e->dense16 && (d.nout == 256 || d.nout == 512) && d.kin >= 16 && d.kin % 16 == 0;
+}
+// in_is_dpre / Ynext (pvk_dense_bwd16 only): dY already is this layer's dpre / the epilogue forms the next layer's dpre in dIn
 int run_dense_bwd(pvae_engine* e, Dense& d, const float* Y, const float* dY, float* dIn, float* dpre_out,
-                  PvRepBwd rp = PvRepBwd{}) {
+                  PvRepBwd rp = PvRepBwd{}, bool in_is_dpre = false, const float* Ynext = nullptr, int act_next = PV_ACT_LINEAR) {
     if (rp.dheads && d.kin != 32) return set_err(e, -6, "sampling-gradient tail on a layer of %d inputs", d.kin);
+    if (!rp.dheads && dense16_bwd_ok(e, d)) {
+        const size_t lds = (size_t)(32 * (d.nout + 4) + 4096) * 4;
+        if (d.nout == 512)
+            hipLaunchKernelGGL(pvk_dense_bwd16<512>, dim3(d.kin / 16), dim3(512), lds, e->stream, d.kin, (const float*)d.W.w, d.act, Y, dY,
+                               in_is_dpre ? 1 : 0, dIn, dpre_out, (const PvStep*)e->st, Ynext, act_next);
+        else
+            hipLaunchKernelGGL(pvk_dense_bwd16<256>, dim3(d.kin / 16), dim3(512), lds, e->stream, d.kin, (const float*)d.W.w, d.act, Y, dY,
+                               in_is_dpre ? 1 : 0, dIn, dpre_out, (const PvStep*)e->st, Ynext, act_next);
+        return launch_check(e, "dense_bwd16");
+    }
+    if (in_is_dpre || Ynext) return set_err(e, -6, "chained dpre on a layer the 32-unit kernel handles");
     hipLaunchKernelGGL(pvk_dense_bwd, dim3(d.kin / 32), dim3(256), lds_dense_bwd(d.nout), e->stream, d.kin, d.W.w, d.nout,
                        d.act, Y, dY, dIn, dpre_out, e->st, rp);
     return launch_check(e, "dense_bwd");
@@ -884,10 +915,18 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
         float* bufs[2] = {e->dA, e->dB};
         int pp = 0;
         size_t li = 0;
+        // Consecutive hidden layers chain through dpre: the producer's epilogue forms the consumer's dpre in the consumer's dpre
+        // buffer (what the Adam launch reads) and the consumer stages it as it comes -- no pass over Y and no act' in between
+        bool chained = false;  // dY is already the dpre of the layer about to run
         for (int i = D - 1; i >= 1; --i) {
-            if ((rc = run_dense_bwd(e, e->dec[i], e->g[i], dY, bufs[pp], e->dpre_bufs[li++]))) return rc;
-            dY = bufs[pp];
-            pp ^= 1;
+            const bool to_next = i - 1 >= 1 && dense16_bwd_ok(e, e->dec[i]) && dense16_bwd_ok(e, e->dec[i - 1]);
+            float* dst = to_next ? e->dpre_bufs[li + 1] : bufs[pp];
+            if ((rc = run_dense_bwd(e, e->dec[i], e->g[i], dY, dst, e->dpre_bufs[li], PvRepBwd{}, chained,
+                                    to_next ? e->g[i - 1] : nullptr, e->dec[i - 1].act))) return rc;
+            ++li;
+            dY = dst;
+            chained = to_next;
+            if (!to_next) pp ^= 1;
         }
         if (e->Kz == 32) {  // one workgroup: dz -> d heads in the tail
             const PvRepBwd rp{e->headout, e->eps, e->dheads, e->Kh, e->K};
@@ -901,10 +940,16 @@ int stage_c(pvae_engine* e, int mode, float* d_out3, bool fuse = false, int next
         if ((rc = run_dense_bwd(e, e->heads, e->headout, e->dheads, bufs[pp], e->dpre_bufs[li++]))) return rc;
         dY = bufs[pp];
         pp ^= 1;
+        chained = false;
         for (int i = D - 2; i >= 0; --i) {
-            if ((rc = run_dense_bwd(e, e->enc[i], e->h[i + 1], dY, bufs[pp], e->dpre_bufs[li++]))) return rc;
-            dY = bufs[pp];
-            pp ^= 1;
+            const bool to_next = i - 1 >= 0 && dense16_bwd_ok(e, e->enc[i]) && dense16_bwd_ok(e, e->enc[i - 1]);
+            float* dst = to_next ? e->dpre_bufs[li + 1] : bufs[pp];
+            if ((rc = run_dense_bwd(e, e->enc[i], e->h[i + 1], dY, dst, e->dpre_bufs[li], PvRepBwd{}, chained,
+                                    to_next ? e->h[i] : nullptr, to_next ? e->enc[i - 1].act : (int)PV_ACT_LINEAR))) return rc;
+            ++li;
+            dY = dst;
+            chained = to_next;
+            if (!to_next) pp ^= 1;
         }
         // weight / bias gradients + Adam of all narrow layers: one launch, one wave per 32x32 block
         // one launch: rows 0 .. n_bwd_ops-1 of the grid are the Adam units, the last row the first (wide) layer's dpre / bias
@@ -1596,6 +1641,7 @@ int pvae_create(const pvae_config* cfg, pvae_engine** out) {
     }
     e->fuse_fwd = !getenv("PVAE_NO_FUSE_FWD");
     e->dec3b = !getenv("PVAE_NO_DEC3B");
+    e->dense16 = !getenv("PVAE_NO_DENSE16");
     e->use_xrn = getenv("PVAE_XRN") != nullptr;
     e->gather_ahead = e->fuse_fwd && !e->use_xrn && getenv("PVAE_GATHER_AHEAD") != nullptr;
     if (e->gather_ahead) {

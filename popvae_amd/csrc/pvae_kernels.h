@@ -608,6 +608,73 @@ __global__ __launch_bounds__(256) void pvk_dense_fwd(const float* __restrict__ i
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same layer for contraction lengths 256 / 512 (the hidden layers at widths above 128), round 3: SIXTEEN output columns per
+// workgroup and eight waves that split the contraction (v_mfma_f32_16x16x4_f32, two 16-row tiles per wave).  A layer is a few
+// microseconds of which the matrix instructions were 1.75 (32 columns per workgroup, four waves: 64 dependent instructions of 64
+// cycles per wave); with twice the workgroups a CU's matrix pipe has half the work (0.87 us) and draws half the weights (32 KB).
+// The input tile sits in LDS with a row stride of K + 4 floats: the A operand reads of a wave (lane (row, quarter) reads word
+// row * (K + 4) + k + quarter) then fall on 64 different banks, and the staging writes are whole float4s.
+// grid = N / 16, 512 threads; LDS = 32 x (K + 4) + 8 x 2 x 4 x 64 floats.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4_mfma __attribute__((ext_vector_type(4)));
+template <int K>
+__global__ __launch_bounds__(512) void pvk_dense_fwd16(const float* __restrict__ in, const float* __restrict__ Wt,
+                                                       const float* __restrict__ bias, int N, int act, float* __restrict__ out,
+                                                       const float* __restrict__ in_bias, float* __restrict__ in_act) {
+    static_assert(K == 256 || K == 512, "contraction lengths of the hidden layers at widths 256 / 512");
+    constexpr int LD = K + 4, KPER = K / 8, S = KPER / 4, NU = 32 * K / 4 / 512;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* in_s = smem;             // [32][LD]
+    float* red = smem + 32 * LD;    // [8 waves][2 tiles][4][64]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * 16, k0 = wave * KPER;
+    // one round trip: this wave's weights (S loads), then the input tile (NU float4 per thread), then the first wait
+    float b[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) b[s] = Wt[(int64_t)(k0 + 4 * s + q) * N + n0 + n];
+    f32x4 v[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) v[u] = reinterpret_cast<const f32x4*>(in)[tid + 512 * u];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int i = 4 * (tid + 512 * u), row = i / K, col = i % K;
+        f32x4 x = v[u];
+        if (in_bias) {  // the input is a pre-activation: elu(in + in_bias), written out by workgroup 0 (pvk_dense_fwd)
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(in_bias + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = pv_elu(x[e] + bq[e]);
+            if (blockIdx.x == 0) *reinterpret_cast<f32x4*>(in_act + i) = x;
+        }
+        *reinterpret_cast<f32x4*>(in_s + row * LD + col) = x;
+    }
+    __syncthreads();
+    f32x4_mfma acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const float a0 = in_s[n * LD + k0 + 4 * s + q], a1 = in_s[(16 + n) * LD + k0 + 4 * s + q];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[s], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[((wave * 2 + 0) * 4 + r) * 64 + lane] = acc0[r];
+        red[((wave * 2 + 1) * 4 + r) * 64 + lane] = acc1[r];
+    }
+    __syncthreads();
+    // 512 outputs, one per thread: element (tile t, register r, lane l) = row 16 t + 4 (l >> 4) + r, column n0 + (l & 15); the eight
+    // waves' partial sums are added in wave order
+    {
+        const int t = tid >> 8, r = (tid >> 6) & 3, l = tid & 63;
+        float sum = red[((0 * 2 + t) * 4 + r) * 64 + l];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) sum += red[((w * 2 + t) * 4 + r) * 64 + l];
+        const int row = 16 * t + 4 * (l >> 4) + r, col = n0 + (l & 15);
+        const float x = sum + bias[col];
+        out[row * N + col] = act == PV_ACT_ELU ? pv_elu(x) : x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Narrow dense layer backward, chain part (widths above 128).  grid = K/32 workgroups (one per 32 input units):
 //   dpre = dY * act'(Y)  (workgroup 0 also writes it to dpre_out for pvk_narrow_adam);
 //   dIn[:, k-block] = dpre * Wt[k-block,:]^T.
@@ -704,6 +771,90 @@ __global__ __launch_bounds__(256) void pvk_dense_bwd(int K, const float* __restr
                 }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The backward of the hidden layers at widths 256 / 512 (N = the layer's outputs = the contraction length here), round 3:
+// SIXTEEN input units per workgroup, eight waves that split the contraction (v_mfma_f32_16x16x4_f32).  Twice the workgroups of
+// pvk_dense_bwd, half the matrix work (0.87 us instead of 1.75) and half the weights (32 KB, float4 loads along the rows of W) per
+// CU.  Contraction step (s, e) of a wave pairs slot q of the instruction with output unit nb + 16 s + 4 q + e, so that a lane's
+// four A operands of a group are ONE ds_read_b128 and its four B operands one global float4.
+// Two ways of chaining layers without a pass over Y in between:
+//   in_is_dpre != 0: dY already IS dpre of this layer (the producer's epilogue below formed it): staged as it comes, 64 KB per
+//                    workgroup instead of dY and Y, nothing written to dpre_out;
+//   Ynext != NULL:   the epilogue turns dIn straight into the NEXT layer's dpre = dIn * act'(Ynext), rows beyond the batch zeroed
+//                    (Ynext = that layer's output = this layer's input activation, [32][K]), and `dIn` is that layer's dpre buffer
+//                    (what pvk_narrow_adam_bias reads) -- as the fused chain does at widths up to 128.
+// grid = K / 16, 512 threads; LDS = 32 x (N + 4) + 8 x 2 x 4 x 64 floats.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(512) void pvk_dense_bwd16(int K, const float* __restrict__ Wt, int act, const float* __restrict__ Y,
+                                                       const float* __restrict__ dY, int in_is_dpre, float* __restrict__ dIn,
+                                                       float* __restrict__ dpre_out, const PvStep* st,
+                                                       const float* __restrict__ Ynext, int act_next) {
+    static_assert(N == 256 || N == 512, "widths 256 / 512");
+    constexpr int LD = N + 4, NPER = N / 8, S4 = NPER / 16, NU = 32 * N / 4 / 512;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dp_s = smem;            // [32][LD]
+    float* red = smem + 32 * LD;   // [8 waves][2 tiles][4][64]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+    const int k0 = blockIdx.x * 16, nb = wave * NPER;
+    const int nrows = st->nrows;
+    f32x4 wv[S4];
+#pragma unroll
+    for (int s = 0; s < S4; ++s) wv[s] = *reinterpret_cast<const f32x4*>(Wt + (int64_t)(k0 + j) * N + nb + 16 * s + 4 * q);
+    f32x4 dv[NU], yv[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        dv[u] = reinterpret_cast<const f32x4*>(dY)[tid + 512 * u];
+        if (!in_is_dpre && act == PV_ACT_ELU) yv[u] = reinterpret_cast<const f32x4*>(Y)[tid + 512 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int i = 4 * (tid + 512 * u), row = i / N, col = i % N;
+        f32x4 x = dv[u];
+        if (!in_is_dpre) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d = row < nrows ? x[e] : 0.f;
+                if (act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[u][e]);
+                x[e] = d;
+            }
+            if (blockIdx.x == 0) *reinterpret_cast<f32x4*>(dpre_out + i) = x;
+        }
+        *reinterpret_cast<f32x4*>(dp_s + row * LD + col) = x;
+    }
+    __syncthreads();
+    f32x4_mfma acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S4; ++s) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(dp_s + j * LD + nb + 16 * s + 4 * q);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(dp_s + (16 + j) * LD + nb + 16 * s + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], wv[s][e], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], wv[s][e], acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[((wave * 2 + 0) * 4 + r) * 64 + lane] = acc0[r];
+        red[((wave * 2 + 1) * 4 + r) * 64 + lane] = acc1[r];
+    }
+    __syncthreads();
+    {
+        const int t = tid >> 8, r = (tid >> 6) & 3, l = tid & 63;
+        float sum = red[((0 * 2 + t) * 4 + r) * 64 + l];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) sum += red[((w * 2 + t) * 4 + r) * 64 + l];
+        const int row = 16 * t + 4 * (l >> 4) + r, col = k0 + (l & 15);
+        if (Ynext) {
+            float d = row < nrows ? sum : 0.f;
+            if (act_next == PV_ACT_ELU) d *= pv_elu_grad_from_out(Ynext[row * K + col]);
+            sum = d;
+        }
+        dIn[row * K + col] = sum;
     }
 }
 
