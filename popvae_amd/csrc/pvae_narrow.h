@@ -88,7 +88,10 @@ __device__ __forceinline__ const pvn_gf4* pvn_g4(const float* p) { return (const
 #define PVN_MAXOPS 64
 // LDS of a worker: two activation buffers, the two-slot ring of layer kernels (64 KB each), the op table
 __host__ __device__ inline size_t pvn_lds_fwd() { return (size_t)(2 * PVQ_LDA + 2 * 128 * 128) * 4 + PVN_MAXOPS * sizeof(PvFwdOp); }
-__host__ __device__ inline size_t pvn_lds_bwd() { return (size_t)(2 * PVQ_LDA + 2 * 128 * 128) * 4 + PVN_MAXOPS * sizeof(PvBwdOp); }
+// (backward: + two slots of [4 rows][128] floats for the Y rows an op's epilogue multiplies with)
+__host__ __device__ inline size_t pvn_lds_bwd() {
+    return (size_t)(2 * PVQ_LDA + 2 * 128 * 128 + 2 * PVQ_LDA) * 4 + PVN_MAXOPS * sizeof(PvBwdOp);
+}
 
 // The op table is cold in every launch (each step streams gigabytes through the caches in between), and a
 // scalar load that misses to HBM costs ~1-2 us per layer.  So the whole table is copied into LDS with one
@@ -191,6 +194,22 @@ __device__ __forceinline__ void pvq_fill_op(const float* __restrict__ src, int n
     }
 }
 #endif
+// nfloats contiguous floats (a worker's four rows of a layer output Y, a multiple of 128) into an LDS area, split over the two
+// loader waves like a kernel copy; lanes beyond the end take no part
+__device__ __forceinline__ void pvq_fill_rows(const float* __restrict__ src, int nfloats, float* dst, int lw, int lane) {
+#if PVQ_DMA
+    typedef __attribute__((address_space(1))) const void gptr;
+    typedef __attribute__((address_space(3))) void lptr;
+    for (int c = lw; c * 256 < nfloats; c += 2) {
+        if (c * 256 + 4 * lane < nfloats)
+            __builtin_amdgcn_global_load_lds((gptr*)(src + c * 256 + 4 * lane), (lptr*)(dst + c * 256), 16, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+#else
+    for (int c = lw; c * 256 < nfloats; c += 2)
+        if (c * 256 + 4 * lane < nfloats) reinterpret_cast<f32x4*>(dst)[c * 64 + lane] = pvn_g4(src + c * 256)[lane];
+#endif
+}
 // 16 contraction steps: instruction b takes the A operand of block b (lanes 4b .. 4b + 3: rows 0..3 of step 16 j + b) for all
 // 64 columns (cbsz = 4, abid = b); four accumulators in rotation keep dependent instructions four apart
 template <int B>
@@ -380,7 +399,8 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
     float* cur = smem;
     float* nxt = smem + PVQ_LDA;
     float* ring = smem + 2 * PVQ_LDA;
-    int* ops_s = reinterpret_cast<int*>(ring + 2 * PVQ_SLOT_FLOATS);
+    float* ys = ring + 2 * PVQ_SLOT_FLOATS;  // two slots of [4 rows][<= 128]: Y of the layer whose dpre an op's epilogue forms
+    int* ops_s = reinterpret_cast<int*>(ys + 2 * PVQ_LDA);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const bool loader = wave >= 2;
     const int h = wave & 1;
@@ -411,7 +431,16 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
 
     PvBwdOp op = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, 0);
     auto chunks = [](const PvBwdOp& o) { return (int)(pvn_wb_floats(o.kin, o.nout) >> 8); };
+    // The epilogue of a dense op o multiplies with act'(Y) of its successor's layer (Y = [rows][o.kin]).  The LOADERS bring the
+    // worker's four rows of it into LDS one op ahead, with the kernel (the barrier that hands over the ring slot covers them): the
+    // consumers have no vector-memory load left in their stream (requested by the consumers at the top of the op, the four words
+    // queued behind the loaders' 64 KB and came back after the matrix instructions were done)
+    auto needs_y = [](const PvBwdOp& o, const PvBwdOp& o_next) {
+        return o.kind == PVN_DENSE && o_next.kind != PVN_REPARAM && o_next.act == PV_ACT_ELU;
+    };
     if (loader) {
+        const PvBwdOp nx0 = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, nops > 1 ? 1 : 0);
+        if (needs_y(op, nx0)) pvq_fill_rows(nx0.Y + rb * op.kin, PVQ_ROWS * op.kin, ys, h, lane);
         if (op.kind == PVN_DENSE) pvq_fill_op(op.Wb, chunks(op), ring, h, lane);
     } else if (n < W0) {  // dpre of the first op from the exchanged decoder feedback
         float xv[PVQ_ROWS], yv[PVQ_ROWS];
@@ -440,6 +469,8 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
         const float* wslot = ring + (i & 1) * PVQ_SLOT_FLOATS;
         float* nslot = ring + ((i + 1) & 1) * PVQ_SLOT_FLOATS;
         if (loader) {
+            const PvBwdOp nx2 = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, i + 2 < nops ? i + 2 : nops - 1);
+            if (needs_y(nx, nx2)) pvq_fill_rows(nx2.Y + rb * nx.kin, PVQ_ROWS * nx.kin, ys + ((i + 1) & 1) * PVQ_LDA, h, lane);
             if (nx.kind == PVN_DENSE) pvq_fill_op(nx.Wb, chunks(nx), nslot, h, lane);
         } else if (op.kind == PVN_REPARAM) {
             PVN_T(128 + i * 8 + 0);
@@ -468,11 +499,7 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
             const int Kin = op.kin;
             const bool to_dpre = nx.kind != PVN_REPARAM;  // REPARAM consumes the raw dz
             const bool mine = n < Kin;
-            float yv[PVQ_ROWS];
-            if (mine && to_dpre && nx.act == PV_ACT_ELU) {
-#pragma unroll
-                for (int r = 0; r < PVQ_ROWS; ++r) yv[r] = pvn_g(nx.Y)[(rb + r) * Kin + n];
-            }
+            const float* ysl = ys + (i & 1) * PVQ_LDA;  // [4 rows][Kin], brought in by the loaders during the previous op
             f32x4 acc;
             PVN_T(128 + i * 8 + 1);
             const f32x4* w_lds = reinterpret_cast<const f32x4*>(wslot) + h * (op.nout >> 2) * 64 + lane;
@@ -488,7 +515,7 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
                 for (int r = 0; r < PVQ_ROWS; ++r) {
                     float d = acc[r];
                     if (to_dpre) {
-                        if (nx.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(yv[r]);
+                        if (nx.act == PV_ACT_ELU) d *= pv_elu_grad_from_out(ysl[r * Kin + n]);
                         if (rb + r >= nrows) d = 0.f;
                         pvn_g(nx.dpre)[(rb + r) * Kin + n] = d;
                     }
