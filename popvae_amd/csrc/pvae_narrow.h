@@ -172,8 +172,9 @@ __device__ __forceinline__ void pvq_fill_op(const float* __restrict__ src, int n
     const int n = nchunks >> 1;  // chunks per loader: contraction lengths and widths are multiples of 32, so a multiple of 4
 #pragma unroll 4
     for (int i = 0; i < n; ++i) __builtin_amdgcn_global_load_lds((gptr*)(s + 512 * i), (lptr*)(d + 512 * i), 16, 0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the chunks are in LDS
 }
+// ... and the loaders' wait for everything they requested (vmcnt(0): the chunks are in LDS), once per op, before the barrier
+__device__ __forceinline__ void pvq_fill_wait() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 #else
 template <int N>
 __device__ __forceinline__ void pvq_fill(const float* __restrict__ src, float* slot, int lw, int lane) {
@@ -193,6 +194,7 @@ __device__ __forceinline__ void pvq_fill_op(const float* __restrict__ src, int n
         default: pvq_fill<32>(src, slot, lw, lane); break;
     }
 }
+__device__ __forceinline__ void pvq_fill_wait() {}
 #endif
 // nfloats contiguous floats (a worker's four rows of a layer output Y, a multiple of 128) into an LDS area, split over the two
 // loader waves like a kernel copy; lanes beyond the end take no part
@@ -204,7 +206,6 @@ __device__ __forceinline__ void pvq_fill_rows(const float* __restrict__ src, int
         if (c * 256 + 4 * lane < nfloats)
             __builtin_amdgcn_global_load_lds((gptr*)(src + c * 256 + 4 * lane), (lptr*)(dst + c * 256), 16, 0, 0);
     }
-    __builtin_amdgcn_s_waitcnt(0x0f70);
 #else
     for (int c = lw; c * 256 < nfloats; c += 2)
         if (c * 256 + 4 * lane < nfloats) reinterpret_cast<f32x4*>(dst)[c * 64 + lane] = pvn_g4(src + c * 256)[lane];
@@ -301,7 +302,10 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
     }
     PvFwdOp op = pvn_get_op<PvFwdOp>(ops_s, op0);
     auto chunks = [](const PvFwdOp& o) { return (int)(pvn_wf_floats(o.kin, o.nout) >> 8); };
-    if (loader && op.kind == PVN_DENSE) pvq_fill_op(op.W, chunks(op), ring, h, lane);
+    if (loader) {
+        if (op.kind == PVN_DENSE) pvq_fill_op(op.W, chunks(op), ring, h, lane);
+        pvq_fill_wait();
+    }
     pvn_lds_barrier();
     for (int i = op0; i < nops; ++i) {
         const PvFwdOp nx = i + 1 < nops ? pvn_get_op<PvFwdOp>(ops_s, i + 1) : op;
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
         if (loader) {
             // op i + 1's kernel into the other slot (free since the barrier behind op i - 1)
             if (i + 1 < nops && nx.kind == PVN_DENSE) pvq_fill_op(nx.W, chunks(nx), nslot, h, lane);
+            pvq_fill_wait();
             if (op.kind == PVN_REPARAM) pvn_lds_barrier();  // the consumers' sync point inside that op
         } else if (op.kind == PVN_REPARAM) {
             PVN_T(i * 8 + 0);
@@ -337,9 +342,9 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_fwd(const PvFwdOp* __r
             }
         } else if (h * 64 < N) {
             PVN_T(i * 8 + 0);
-            // this op's bias: issued here, complete when the epilogue needs it (op.b is never null).  (Requested one op ahead,
-            // before the barrier -- and likewise the Y words of the backward chain's epilogue -- was measured slower: 20.1 / 22.9
-            // against 19.0 / 22.2 us per chain.)
+            // this op's bias: issued here, complete when the epilogue needs it (op.b is never null).  (Requested one op ahead by
+            // the consumer, or brought into LDS by the loaders with the kernel as the backward chain's Y rows are, was measured
+            // slower both times: 20.1 / 19.9 against 19.0 us per chain.)
             const float bcur = pvn_g(op.b)[n < N ? n : 0];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             if (op.kind == PVN_BIAS_ACT) {
@@ -442,6 +447,7 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
         const PvBwdOp nx0 = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, nops > 1 ? 1 : 0);
         if (needs_y(op, nx0)) pvq_fill_rows(nx0.Y + rb * op.kin, PVQ_ROWS * op.kin, ys, h, lane);
         if (op.kind == PVN_DENSE) pvq_fill_op(op.Wb, chunks(op), ring, h, lane);
+        pvq_fill_wait();
     } else if (n < W0) {  // dpre of the first op from the exchanged decoder feedback
         float xv[PVQ_ROWS], yv[PVQ_ROWS];
 #pragma unroll
@@ -472,6 +478,7 @@ __global__ __launch_bounds__(PVQ_THREADS) void pvk_narrow_bwd(const PvBwdOp* __r
             const PvBwdOp nx2 = pvn_get_op_lean<PvBwdOp, PVN_BWD_LEAN>(ops_s, i + 2 < nops ? i + 2 : nops - 1);
             if (needs_y(nx, nx2)) pvq_fill_rows(nx2.Y + rb * nx.kin, PVQ_ROWS * nx.kin, ys + ((i + 1) & 1) * PVQ_LDA, h, lane);
             if (nx.kind == PVN_DENSE) pvq_fill_op(nx.Wb, chunks(nx), nslot, h, lane);
+            pvq_fill_wait();
         } else if (op.kind == PVN_REPARAM) {
             PVN_T(128 + i * 8 + 0);
             // cur = dz [Kz][rows]; result: dpre of the heads op [Kh][rows] (k in [0,K) dmu, [K,2K) ds, rest 0)
