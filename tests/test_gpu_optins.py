@@ -3,7 +3,9 @@
    PVAE_XRN=1        the step head gathers the NEXT batch into compact words for the forward fused into pvk_enc_bwd -- bit-identical;
    PVAE_GATHER_AHEAD=1  the next batch is gathered by a launch of its own on a second stream, beside the forward chain -- bit-identical;
    PVAE_NO_DEC3B=1   four row tiles through the fp32 decoder training kernel instead of pvk_dec3b -- same result to 1e-4 (the
-                     two kernels sum in different orders).
+                     two kernels sum in different orders);
+   PVAE_NO_DENSE16=1 widths 256 / 512: the 32-unit per-layer kernels instead of pvk_dense_fwd16 / pvk_dense_bwd16 (and no chaining of
+                     the backward through dpre) -- same moments to 1e-5 at a learning rate that keeps the two runs on one trajectory.
 Measured slower or equal, kept for A/B comparisons; these tests keep them working."""
 import os
 
@@ -68,3 +70,13 @@ def test_fp32_decoder_pass_at_four_tiles_agrees_with_the_bf16_one():
     assert np.allclose(ref[0], got[0], rtol=1e-5), (ref[0], got[0])
     for a, b in zip(ref[1], got[1]):
         assert np.max(np.abs(a - b)) <= 1e-4 * max(np.max(np.abs(a)), 1e-6) + 2e-6  # weights after ~6 Adam steps of 1e-4
+
+
+@pytest.mark.parametrize("L,W,D", [(3000, 512, 4), (2077, 256, 6), (1000, 200, 2)])
+def test_32_unit_per_layer_kernels_agree_with_the_16_unit_ones(L, W, D):
+    # (ragged last batch: 135 training rows = 4 x 32 + 7; validation rows through the read-only pass)
+    ref = _run({}, 150, L, W, D, 32, 2, lr=1e-5)
+    got = _run({"PVAE_NO_DENSE16": "1"}, 150, L, W, D, 32, 2, lr=1e-5)
+    assert np.allclose(ref[0], got[0], rtol=2e-6), (ref[0], got[0])
+    for i, (a, b) in enumerate(zip(ref[2], got[2])):
+        assert np.abs(a - b).max() <= 1e-5 * max(np.abs(a).max(), 1e-30), (i, np.abs(a - b).max(), np.abs(a).max())
